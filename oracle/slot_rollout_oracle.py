@@ -1,0 +1,331 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU (fp32, torch-CPU tensor arithmetic) restatement of the reference's autoregressive slot-rollout
+hot path: SAVi encode -> slot attention -> transition -> TextOCVP rollout -> spatial-broadcast decode.
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
+this file; the product (``textocvp_amd``) must never route through it.
+
+Every function works on a flat ``dict`` of weights keyed exactly like the reference's
+``state_dict``, so it is independent of this repo's module mirrors.
+Citations are ``path:line`` relative to the reference root (/root/reference/src/...).
+
+Pinning: checked against golden vectors produced by importing the reference itself in the build
+container (tests/golden/make_golden.py -> tests/golden/*.npz; tests/test_oracle_golden.py).
+"""
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "layer_norm", "linear", "build_grid", "savi_encode", "slot_attention", "transition_block",
+    "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
+    "forward_eval", "sub",
+]
+
+
+def sub(sd, prefix):
+    """ view of the weight dict below ``prefix`` (with the prefix stripped) """
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# ------------------------------------------------------------------------------------------------
+# elementary ops (torch.nn semantics the reference relies on; SURVEY.md 8c "torch itself")
+# ------------------------------------------------------------------------------------------------
+
+def layer_norm(x, w, b, eps):
+    """ nn.LayerNorm over the last axis, biased variance. """
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def linear(x, w, b=None):
+    """ nn.Linear: y = x W^T + b, W stored (out, in). """
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def gelu(x):
+    """ exact (erf) GELU, the default of nn.TransformerEncoderLayer(activation='gelu') """
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def attention(q, k, v, heads, scale, key_mask=None):
+    """
+    Multi-head softmax(q k^T * scale) v on (B, T, H*dh) tensors.
+    models/Blocks/attention.py:183-215 (attention / split_into_heads / merge_heads).
+    key_mask: optional bool (B, Tk), True = key is padding (excluded).
+    """
+    B, Tq, E = q.shape
+    Tk = k.shape[1]
+    dh = E // heads
+    qh = q.reshape(B, Tq, heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, heads, dh).permute(0, 2, 1, 3)
+    dots = (qh @ kh.transpose(-1, -2)) * scale                     # (B, H, Tq, Tk)
+    if key_mask is not None:
+        dots = dots.masked_fill(key_mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(dots, dim=-1)
+    o = p @ vh                                                     # (B, H, Tq, dh)
+    return o.permute(0, 2, 1, 3).reshape(B, Tq, E)
+
+
+# ------------------------------------------------------------------------------------------------
+# SAVi encoder  (models/SAVi.py:226-238)
+# ------------------------------------------------------------------------------------------------
+
+def build_grid(resolution):
+    """ models/Blocks/model_utils.py:12-34 -> (1, H, W, 4) fp32: [g_y, g_x, 1-g_y, 1-g_x] """
+    ranges = [np.linspace(-1.0, 1.0, num=r) for r in resolution]
+    g = np.stack(np.meshgrid(*ranges, sparse=False, indexing="ij"), axis=-1)
+    g = g.reshape(resolution[0], resolution[1], -1)[None].astype(np.float32)
+    return torch.from_numpy(np.concatenate([g, 1.0 - g], axis=-1))
+
+
+def soft_pos_embed(proj_w, proj_b, resolution):
+    """ models/Blocks/model_blocks.py:186-226: Conv1x1(grid) as an (H, W, C) addend. """
+    grid = build_grid(resolution)[0]                               # (H, W, 4)
+    return grid @ proj_w.reshape(proj_w.shape[0], 4).t() + proj_b  # (H, W, C)
+
+
+def savi_encode(sd, imgs):
+    """
+    models/SAVi.py:226-238 + EncodersDecoders/encoders.py:99-159 + SAVi.py:115-120.
+    imgs (B, 3, H, W) -> feats (B, H*W, mlp_encoder_dim)
+    """
+    x = imgs
+    i = 0
+    while f"encoder.encoder.{i}.block.0.weight" in sd:
+        w, b = sd[f"encoder.encoder.{i}.block.0.weight"], sd[f"encoder.encoder.{i}.block.0.bias"]
+        x = torch.relu(F.conv2d(x, w, b, padding=w.shape[-1] // 2))
+        i += 1
+    x = x.permute(0, 2, 3, 1)                                      # (B, H, W, C)
+    H, W = x.shape[1:3]
+    x = x + soft_pos_embed(sd["encoder_pos_embedding.projection.weight"],
+                           sd["encoder_pos_embedding.projection.bias"], (H, W))
+    x = x.flatten(1, 2)
+    x = layer_norm(x, sd["encoder_mlp.0.weight"], sd["encoder_mlp.0.bias"], 1e-5)
+    x = torch.relu(linear(x, sd["encoder_mlp.1.weight"], sd["encoder_mlp.1.bias"]))
+    x = linear(x, sd["encoder_mlp.3.weight"], sd["encoder_mlp.3.bias"])
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Slot attention + transition  (models/Blocks/attention.py:67-112, 371-396)
+# ------------------------------------------------------------------------------------------------
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """ torch.nn.GRUCell, gate order (r, z, n). """
+    gi = linear(x, w_ih, b_ih)
+    gh = linear(h, w_hh, b_hh)
+    D = h.shape[-1]
+    r = torch.sigmoid(gi[..., :D] + gh[..., :D])
+    z = torch.sigmoid(gi[..., D:2 * D] + gh[..., D:2 * D])
+    n = torch.tanh(gi[..., 2 * D:] + r * gh[..., 2 * D:])
+    return (1.0 - z) * n + z * h
+
+
+def slot_attention(sd, feats, slots, num_iters, eps=1e-8, return_attn=False):
+    """
+    models/Blocks/attention.py:67-112 with ``sd`` = weights below 'slot_attention.'.
+    feats (B, N, Df), slots (B, K, D) -> slots (B, K, D).  scale uses dim_FEATS (:46).
+    """
+    scale = feats.shape[-1] ** -0.5
+    x = layer_norm(feats, sd["norm_input.weight"], sd["norm_input.bias"], 1e-3)
+    k = linear(x, sd["to_k.weight"], sd["to_k.bias"])
+    v = linear(x, sd["to_v.weight"], sd["to_v.bias"])
+    attn = None
+    for _ in range(num_iters):
+        prev = slots
+        s = layer_norm(slots, sd["norm_slot.weight"], sd["norm_slot.bias"], 1e-3)
+        q = linear(s, sd["to_q.weight"], sd["to_q.bias"])
+        dots = (q @ k.transpose(1, 2)) * scale                     # (B, K, N)
+        attn = torch.softmax(dots, dim=1) + eps                    # softmax ACROSS SLOTS (:100)
+        w = attn / attn.sum(dim=-1, keepdim=True)
+        upd = w @ v                                                # (B, K, D)
+        slots = gru_cell(upd, prev, sd["gru.weight_ih"], sd["gru.weight_hh"],
+                         sd["gru.bias_ih"], sd["gru.bias_hh"])
+        m = layer_norm(slots, sd["norm_mlp.weight"], sd["norm_mlp.bias"], 1e-3)
+        m = torch.relu(linear(m, sd["mlp.0.weight"], sd["mlp.0.bias"]))
+        slots = slots + linear(m, sd["mlp.2.weight"], sd["mlp.2.bias"])
+    return (slots, attn) if return_attn else slots
+
+
+def mhsa(sd, x, heads):
+    """ models/Blocks/attention.py:245-265; q/k/v/out bias-free. """
+    q, k, v = linear(x, sd["q.weight"]), linear(x, sd["k.weight"]), linear(x, sd["v.weight"])
+    dh = x.shape[-1] // heads
+    o = attention(q, k, v, heads, dh ** -0.5)
+    return linear(o, sd["out_projection.0.weight"])
+
+
+def transition_block(sd, x, heads):
+    """ post-norm TransformerBlock, models/Blocks/attention.py:387-395 (LN eps 1e-6). """
+    if not sd:
+        return x                                                   # nn.Identity transition
+    y = mhsa(sub(sd, "attn."), x, heads) + x
+    y = layer_norm(y, sd["layernorm_query.weight"], sd["layernorm_query.bias"], 1e-6)
+    z = linear(torch.relu(linear(y, sd["mlp.0.weight"], sd["mlp.0.bias"])),
+               sd["mlp.2.weight"], sd["mlp.2.bias"]) + y
+    return layer_norm(z, sd["layernorm_mlp.weight"], sd["layernorm_mlp.bias"], 1e-6)
+
+
+def savi_decomp(sd, videos, noise, num_imgs, iters_first=3, iters=1, trans_heads=4):
+    """
+    models/SAVi.py:152-223 with decode=False: videos (B, L, C, H, W) -> slot_history (B, T, K, D).
+    ``noise`` (B, K, D) stands for the torch.randn draw of initializers.py:87-94.
+    slot_history stores the corrector output (pre-transition), SAVi.py:192-198,212.
+    """
+    if "initializer.slots_mu" in sd:
+        pred = sd["initializer.slots_mu"] + sd["initializer.slots_sigma"] * noise
+    else:                                                          # 'Learned' initializer :58-61
+        pred = sd["initializer.slots"].expand(videos.shape[0], -1, -1)
+    sa, tr = sub(sd, "slot_attention."), sub(sd, "transition_module.")
+    hist = []
+    for t in range(num_imgs):
+        feats = savi_encode(sd, videos[:, t])
+        slots = slot_attention(sa, feats, pred, iters_first if t == 0 else iters)
+        pred = transition_block(tr, slots, trans_heads)
+        hist.append(slots)
+    return torch.stack(hist, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# SAVi decoder  (models/SAVi.py:241-275, EncodersDecoders/decoders.py:85-120)
+# ------------------------------------------------------------------------------------------------
+
+def savi_decode(sd, slots, resolution=(64, 64), in_channels=3):
+    """ slots (B', K, D) -> recons_imgs (B',3,H,W), recons (B',K,3,H,W), masks (B',K,1,H,W) """
+    Bp, K, D = slots.shape
+    pos = soft_pos_embed(sd["decoder_pos_embedding.projection.weight"],
+                         sd["decoder_pos_embedding.projection.bias"], resolution)  # (H, W, D)
+    x = slots.reshape(Bp * K, 1, 1, D) + pos[None]                 # broadcast + pos (:264-275)
+    x = x.permute(0, 3, 1, 2)
+    i = 0
+    while f"decoder.decoder.{i}.block.0.weight" in sd:
+        w, b = sd[f"decoder.decoder.{i}.block.0.weight"], sd[f"decoder.decoder.{i}.block.0.bias"]
+        x = torch.relu(F.conv2d(x, w, b, padding=w.shape[-1] // 2))
+        i += 1
+    w, b = sd[f"decoder.decoder.{i}.weight"], sd[f"decoder.decoder.{i}.bias"]
+    y = F.conv2d(x, w, b, padding=1)                               # (B'K, 4, H, W)
+    y = y.reshape(Bp, K, in_channels + 1, y.shape[2], y.shape[3])
+    recons, alpha = y[:, :, :in_channels], y[:, :, in_channels:]
+    masks = torch.softmax(alpha, dim=1)                            # softmax over slots (:254)
+    return (recons * masks).sum(dim=1), recons, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# Text encoder  (models/EncodersDecoders/text_encoders.py:89-125)
+# ------------------------------------------------------------------------------------------------
+
+def text_encoder(sd, tokens, lengths, heads=4):
+    """
+    tokens (B, L) int64, lengths (B,) -> (B, L, out_dim).  Post-norm nn.TransformerEncoderLayer
+    (GELU, eps 1e-5, key-padding mask) x num_layers; padded positions keep finite values and ARE
+    consumed downstream (no mask in the predictor's cross-attention).
+    """
+    B, L = tokens.shape
+    x = sd["token_embedding.weight"][tokens] + sd["position_embedding.weight"][:L][None]
+    x = layer_norm(x, sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-8)
+    x = x * (tokens != 0).unsqueeze(-1).to(x.dtype)
+    key_pad = torch.arange(1, L + 1)[None, :] > lengths[:, None]   # (B, L) True = padding
+    li = 0
+    while f"transformer.layers.{li}.linear1.weight" in sd:
+        p = sub(sd, f"transformer.layers.{li}.")
+        E = x.shape[-1]
+        qkv = linear(x, p["self_attn.in_proj_weight"], p["self_attn.in_proj_bias"])
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+        a = attention(q, k, v, heads, (E // heads) ** -0.5, key_mask=key_pad)
+        a = linear(a, p["self_attn.out_proj.weight"], p["self_attn.out_proj.bias"])
+        x = layer_norm(x + a, p["norm1.weight"], p["norm1.bias"], 1e-5)
+        f = linear(gelu(linear(x, p["linear1.weight"], p["linear1.bias"])),
+                   p["linear2.weight"], p["linear2.bias"])
+        x = layer_norm(x + f, p["norm2.weight"], p["norm2.bias"], 1e-5)
+        li += 1
+    x = layer_norm(x, sd["text_out_projection.0.weight"], sd["text_out_projection.0.bias"], 1e-5)
+    return linear(x, sd["text_out_projection.1.weight"], sd["text_out_projection.1.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# TextOCVP predictor  (models/Predictors/text_cond_OCVP.py:79-105, predictor_wrapper.py:50-87)
+# ------------------------------------------------------------------------------------------------
+
+def adapted_block(sd, x, text, heads=8, cross_heads=8, cross_dh=64):
+    """
+    AdaptedEncoderBlock.forward, models/Blocks/attention.py:504-524 (+ :445-463, :303-319).
+    NOTE the final residual is taken from y (post self-attention), not from the cross-attention
+    branch output.
+    """
+    y = x + mhsa(sub(sd, "attn."), layer_norm(x, sd["layernorm_query.weight"],
+                                              sd["layernorm_query.bias"], 1e-6), heads)
+    c = sub(sd, "cross_attention.")
+    qn = layer_norm(y, c["ln_cross_att_q.weight"], c["ln_cross_att_q.bias"], 1e-6)
+    kv = layer_norm(text, c["ln_cross_att_kv.weight"], c["ln_cross_att_kv.bias"], 1e-6)
+    q = linear(qn, c["cross_attn.q.weight"])
+    k = linear(kv, c["cross_attn.k.weight"])
+    v = linear(kv, c["cross_attn.v.weight"])
+    a = attention(q, k, v, cross_heads, cross_dh ** -0.5)          # no key-padding mask (:314)
+    z = linear(a, c["cross_attn.out_projection.weight"], c["cross_attn.out_projection.bias"]) + y
+    m = layer_norm(z, c["ln_mlp.weight"], c["ln_mlp.bias"], 1e-6)
+    z = linear(torch.relu(linear(m, c["mlp.0.weight"], c["mlp.0.bias"])),
+               c["mlp.2.weight"], c["mlp.2.bias"]) + z
+    m = layer_norm(z, sd["layernorm_mlp.weight"], sd["layernorm_mlp.bias"], 1e-6)
+    return linear(torch.relu(linear(m, sd["mlp.0.weight"], sd["mlp.0.bias"])),
+                  sd["mlp.2.weight"], sd["mlp.2.bias"]) + y
+
+
+def text_ocvp_step(sd, window, text, residual=True):
+    """
+    BaseTextOCVP.forward (text_cond_OCVP.py:79-105) with ``sd`` = weights below 'predictor.'
+    of the PredictorWrapper.  window (B, w, K, D) -> next slots (B, K, D).
+    Temporal PE is FLIPPED: newest frame gets pe[0] (model_blocks.py:375-377).
+    """
+    B, w, K, D = window.shape
+    tok = linear(window, sd["mlp_in.weight"], sd["mlp_in.bias"])   # (B, w, K, E)
+    pe = sd["pe.pe"][0, :w, 0]                                     # (w, E)
+    tok = tok + torch.flip(pe, dims=(0,))[None, :, None, :]
+    tok = tok.reshape(B, w * K, -1)
+    li = 0
+    while f"predictor.{li}.mlp.0.weight" in sd:
+        tok = adapted_block(sub(sd, f"predictor.{li}."), tok, text)
+        li += 1
+    last = tok.reshape(B, w, K, -1)[:, -1]
+    out = linear(last, sd["mlp_out.weight"], sd["mlp_out.bias"])
+    return out + window[:, -1] if residual else out
+
+
+def rollout(sd, slot_history, tokens, lengths, num_context, num_preds, buffer_size=10,
+            teacher_force=False):
+    """ PredictorWrapper.forward, predictor_wrapper.py:50-87 (sd keys start with 'predictor.'). """
+    p = sub(sd, "predictor.")
+    text = text_encoder(sub(p, "text_encoder."), tokens, lengths)
+    window = slot_history[:, :num_context].clone()
+    preds = []
+    for t in range(num_preds):
+        cur = text_ocvp_step(p, window, text)
+        nxt = slot_history[:, num_context + t] if teacher_force else cur
+        window = torch.cat([window, nxt.unsqueeze(1)], dim=1)
+        if window.shape[1] > buffer_size:                          # :143-153
+            window = window[:, window.shape[1] - buffer_size:]
+        preds.append(cur)
+    return torch.stack(preds, dim=1)
+
+
+def forward_eval(savi_sd, pred_sd, videos, tokens, lengths, noise, num_context, num_preds,
+                 buffer_size=10):
+    """
+    The three calls of Evaluator.forward_eval (05_evaluate_predictor.py:82-96) on CPU.
+    Returns slot_history (B,T,K,D), pred_slots (B,P,K,D), pred_imgs (B,P,C,H,W) clamped to [0,1],
+    masks (B*P,K,1,H,W).
+    """
+    B, L, C, H, W = videos.shape
+    hist = savi_decomp(savi_sd, videos, noise, num_context + num_preds)
+    preds = rollout(pred_sd, hist, tokens, lengths, num_context, num_preds, buffer_size)
+    K, D = preds.shape[2:]
+    imgs, _, masks = savi_decode(savi_sd, preds.reshape(B * num_preds, K, D), (H, W), C)
+    return hist, preds, imgs.view(B, num_preds, C, H, W).clamp(0, 1), masks

@@ -1,0 +1,251 @@
+"""
+Golden-vector generator: runs the REFERENCE modules (imported from /root/reference, CPU, fp32)
+on deterministic synthetic weights/inputs and stores small input/output fixtures as .npz.
+
+Only runs in the build container (the reference never travels to the GPU box).  Recipe for the
+import follows SURVEY.md section 8(c): two inert stubs for packages the image lacks (timm, nltk),
+modules constructed directly from the reference's JSON configs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The fixtures hold DATA only (outputs, and the few inputs that are not regenerated from
+textocvp_amd.synth): no reference source text.
+"""
+
+import copy
+import json
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.environ.get("TOCVP_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from textocvp_amd import synth  # noqa: E402
+
+
+def import_reference():
+    """ Make `models.*` of the reference importable (stubs for timm / nltk only). """
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from transformers import T5EncoderModel  # noqa: F401  (must precede the timm stub)
+
+    def _stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:  # placeholder for timm's VisionTransformer symbols
+        pass
+
+    _stub("timm")
+    _stub("timm.models")
+    _stub("timm.models.layers", PatchEmbed=_Dummy, trunc_normal_=lambda *a, **k: None)
+    _stub("timm.models.resnet", ResNet=_Dummy, Bottleneck=_Dummy, BasicBlock=_Dummy)
+    _stub("timm.models.vision_transformer", VisionTransformer=_Dummy,
+          _create_vision_transformer=lambda *a, **k: None)
+    _stub("nltk", download=lambda *a, **k: True, word_tokenize=lambda s: s.split())
+
+    from models.SAVi import SAVi
+    from models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
+    from models.Predictors.predictor_wrapper import PredictorWrapper
+    return SAVi, TextOCVP_CustomTF, PredictorWrapper
+
+
+def load_cfg(rel):
+    with open(os.path.join(REF, "src", "configs", rel)) as f:
+        return json.load(f)
+
+
+def build_reference(num_slots, num_context, num_preds, buffer_size=10, seed=0):
+    """ SAVi + PredictorWrapper(TextOCVP_CustomTF) with synthetic weights, eval mode. """
+    SAVi, TextOCVP_CustomTF, PredictorWrapper = import_reference()
+    savi_cfg = load_cfg("models/SAVi.json")
+    savi_cfg["num_slots"] = num_slots
+    pred_cfg = load_cfg("predictors/TextOCVP_CustomTF.json")
+    savi = SAVi(**copy.deepcopy(savi_cfg)).eval()
+    pp = copy.deepcopy(pred_cfg["predictor_params"])
+    pp["predictor_params"]["input_buffer_size"] = buffer_size
+    core = TextOCVP_CustomTF(
+        slot_dim=savi_cfg["slot_dim"],
+        predictor_params=pp["predictor_params"],
+        fusion_params=pp["fusion_params"],
+        text_encoder_params=pp["text_encoder_params"],
+    )
+    exp_params = {
+        "model": {"model_name": "SAVi", "model_params": copy.deepcopy(savi_cfg)},
+        "predictor": copy.deepcopy(pred_cfg),
+        "prediction_params": {"num_context": num_context, "num_preds": num_preds,
+                              "teacher_force": False, "input_buffer_size": buffer_size},
+    }
+    wrapper = PredictorWrapper(exp_params=exp_params, predictor=core).eval()
+    synth.fill_module_(savi, seed=seed, prefix="savi.")
+    synth.fill_module_(wrapper, seed=seed, prefix="pred.")
+    # the learned temporal PE is a plain attribute holding a Parameter (not in the state_dict
+    # of every torch version): fill it explicitly so both sides agree.
+    pe = wrapper.predictor.pe.pe
+    with torch.no_grad():
+        pe.copy_(synth.synth_tensor("pred.predictor.pe.pe", pe.shape, "normal",
+                                    pe.shape[-1] ** -0.5, seed))
+    return savi, wrapper
+
+
+class FixedNoise:
+    """ Patches torch.randn so the reference's LearnedRandom draws OUR noise tensor. """
+
+    def __init__(self, noise):
+        self.noise = noise
+        self._p = None
+
+    def __enter__(self):
+        noise = self.noise
+
+        def _randn(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else size
+            assert tuple(shape) == tuple(noise.shape), (shape, noise.shape)
+            return noise.clone()
+        self._p = mock.patch("torch.randn", _randn)
+        self._p.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self._p.__exit__(*a)
+
+
+def sub(x, step=16):
+    """ sub-sample the last axis-but-one heavy tensors to keep fixtures small """
+    return x[..., ::step, :]
+
+
+@torch.no_grad()
+def unit_fixtures(out_dir):
+    """ Per-unit goldens at K=7 (SURVEY.md section 4 list). """
+    savi, wrapper = build_reference(num_slots=7, num_context=1, num_preds=4)
+    core = wrapper.predictor
+    B, K, D = 2, 7, 128
+    fx = {}
+
+    # --- a3 encoder ------------------------------------------------------------------------
+    imgs = synth.synth_tensor("unit.imgs", (B, 3, 64, 64), "unit")
+    feats = savi.encode(imgs)                                         # (B, 4096, 128)
+    fx["encoder_feats_sub16"] = feats[:, ::16].numpy()
+
+    # --- a4 slot attention: frame step with 3 iterations (t=0) and 1 iteration (t>0) --------
+    sa_in = synth.synth_tensor("unit.sa_feats", (B, 4096, D), "normal")
+    slots0 = synth.synth_tensor("unit.sa_slots", (B, K, D), "normal")
+    fx["sa_step0"] = savi.slot_attention(sa_in, slots0, step=0).numpy()
+    fx["sa_step0_attn_sub16"] = savi.slot_attention.attention_masks[:, :, ::16].numpy()
+    fx["sa_step1"] = savi.slot_attention(sa_in, slots0, step=1).numpy()
+
+    # --- a5 transition ----------------------------------------------------------------------
+    fx["transition"] = savi.transition_module(slots0).numpy()
+
+    # --- a7 text encoder with ragged lengths {5, 12, 12 padded to 20} ------------------------
+    tokens, lengths = synth.synth_captions(3, max_len=20, lengths=[5, 12, 12], seed=3)
+    fx["text_tokens"] = tokens.numpy()
+    fx["text_lengths"] = lengths.numpy()
+    text_emb = core.text_encoder(text=tokens, text_length=lengths)    # (3, 20, 512)
+    fx["text_emb"] = text_emb.numpy()
+
+    # --- a9 one AdaptedEncoderBlock ----------------------------------------------------------
+    x = synth.synth_tensor("unit.block_x", (3, 2 * K, 512), "normal")
+    fx["block0"] = core.predictor[0](x, text_emb).numpy()
+
+    # --- a8 one predictor step at window 1 and window 10 -------------------------------------
+    win1 = synth.synth_tensor("unit.win1", (3, 1, K, D), "normal")
+    win10 = synth.synth_tensor("unit.win10", (3, 10, K, D), "normal")
+    fx["pred_step_w1"] = core(slots=win1, text_embeddings=text_emb).numpy()
+    fx["pred_step_w10"] = core(slots=win10, text_embeddings=text_emb).numpy()
+
+    # --- a10 decoder at K=7 -------------------------------------------------------------------
+    dslots = synth.synth_tensor("unit.dec_slots", (2, K, D), "normal")
+    out = savi(mode="decode", slots=dslots)
+    fx["dec7_recons_imgs"] = out["recons_imgs"].numpy()
+    fx["dec7_recons_sub4"] = out["recons"][..., ::4, ::4].numpy()
+    fx["dec7_masks_sub4"] = out["masks"][..., ::4, ::4].numpy()
+    np.savez(os.path.join(out_dir, "units_k7.npz"), **fx)
+    print("units_k7:", {k: v.shape for k, v in fx.items()})
+
+    # --- a10 decoder at K=30 ------------------------------------------------------------------
+    savi30, _ = build_reference(num_slots=30, num_context=1, num_preds=19)
+    dslots = synth.synth_tensor("unit.dec_slots30", (2, 30, D), "normal")
+    out = savi30(mode="decode", slots=dslots)
+    fx30 = {
+        "dec30_recons_imgs": out["recons_imgs"].numpy(),
+        "dec30_recons_sub8": out["recons"][..., ::8, ::8].numpy(),
+        "dec30_masks_sub8": out["masks"][..., ::8, ::8].numpy(),
+    }
+    np.savez(os.path.join(out_dir, "units_k30.npz"), **fx30)
+    print("units_k30:", {k: v.shape for k, v in fx30.items()})
+
+
+@torch.no_grad()
+def forward_eval(savi, wrapper, videos, tokens, lengths, noise, num_context, num_preds):
+    """ The three calls of the reference evaluator's forward_eval, on CPU. """
+    B, L, C, H, W = videos.shape
+    with FixedNoise(noise):
+        out_model = savi(mode="decomp", x=videos, num_imgs=num_context + num_preds, decode=False,
+                         caption_tokens=tokens, caption_lengths=lengths)
+    slot_history = out_model["slot_history"]
+    pred_slots = wrapper(slot_history, caption_tokens=tokens, caption_lengths=lengths)
+    K, D = savi.num_slots, savi.slot_dim
+    out_dec = savi(mode="decode", slots=pred_slots.reshape(B * num_preds, K, D))
+    pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
+    return slot_history, pred_slots, pred_imgs, out_dec
+
+
+@torch.no_grad()
+def e2e_fixtures(out_dir):
+    # C1: K=7, B=2, 1 seed + 4 preds, ragged captions (lengths 9 and 12, padded to 12)
+    savi, wrapper = build_reference(num_slots=7, num_context=1, num_preds=4)
+    videos = synth.synth_videos(2, 5, seed=0)
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    sh, ps, pi, od = forward_eval(savi, wrapper, videos, tokens, lengths, noise, 1, 4)
+    np.savez(os.path.join(out_dir, "e2e_c1.npz"), slot_history=sh.numpy(), pred_slots=ps.numpy(),
+             pred_imgs=pi.numpy(), tokens=tokens.numpy(), lengths=lengths.numpy(),
+             masks_argmax=od["masks"].argmax(dim=1).to(torch.uint8).numpy())
+    print("e2e_c1:", sh.shape, ps.shape, pi.shape)
+
+    # C2: K=30, B=1, 1 seed + 19 preds
+    savi, wrapper = build_reference(num_slots=30, num_context=1, num_preds=19)
+    videos = synth.synth_videos(1, 20, seed=0)
+    tokens, lengths = synth.synth_captions(1, max_len=12, seed=0)
+    noise = synth.synth_noise(1, 30, 128, seed=1)
+    sh, ps, pi, od = forward_eval(savi, wrapper, videos, tokens, lengths, noise, 1, 19)
+    np.savez(os.path.join(out_dir, "e2e_c2.npz"), slot_history=sh.numpy(), pred_slots=ps.numpy(),
+             pred_imgs_sub2=pi[..., ::2, ::2].numpy(), tokens=tokens.numpy(),
+             lengths=lengths.numpy(),
+             masks_argmax_sub2=od["masks"].argmax(dim=1)[..., ::2, ::2].to(torch.uint8).numpy())
+    print("e2e_c2:", sh.shape, ps.shape, pi.shape)
+
+
+@torch.no_grad()
+def manifest(out_dir):
+    """ state_dict key/shape manifest = the checkpoint-layout contract. """
+    savi, wrapper = build_reference(num_slots=30, num_context=1, num_preds=19)
+    man = {
+        "SAVi": {k: list(v.shape) for k, v in savi.state_dict().items()},
+        "PredictorWrapper": {k: list(v.shape) for k, v in wrapper.state_dict().items()},
+    }
+    with open(os.path.join(out_dir, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("manifest:", len(man["SAVi"]), len(man["PredictorWrapper"]))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    what = sys.argv[1:] or ["manifest", "units", "e2e"]
+    if "manifest" in what:
+        manifest(HERE)
+    if "units" in what:
+        unit_fixtures(HERE)
+    if "e2e" in what:
+        e2e_fixtures(HERE)
