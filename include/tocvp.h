@@ -1,0 +1,177 @@
+/*
+ * tocvp.h -- C-ABI of libtocvp.so: hand-written HIP (gfx950 / MI355X) kernels for the TextOCVP
+ * autoregressive slot-rollout hot path (SAVi encode -> slot attention -> text-conditioned
+ * predictor -> spatial-broadcast decoder).
+ *
+ * The reference (angelvillar96/TextOCVP) has NO native layer: every op on the path is a stock
+ * ATen call issued from Python.  This header therefore does not
+ * replace an existing FFI; it is the FFI a maintainer would bind from the reference's
+ * src/models modules (ctypes stub in INTEGRATION.md).  Each entry point names the reference
+ * operator(s) it replaces as `path:line` relative to /root/reference/src.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers + sizes; no torch / STL types.
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless stated), row-major,
+ *     feature-last: (B,N,D), (B,K,D), NHWC for conv activations.
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued: no allocation,
+ *     no synchronisation, no global state -> re-entrant per stream and graph-capturable.
+ *   - return 0 on success, a negative TOCVP_E* code otherwise (nothing is enqueued on error).
+ */
+#ifndef TOCVP_H
+#define TOCVP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOCVP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define TOCVP_OK 0
+#define TOCVP_EINVAL (-1)   /* bad argument (null pointer, size, unsupported shape) */
+#define TOCVP_ELAUNCH (-2)  /* hipLaunch reported an error */
+#define TOCVP_EALIGN (-3)   /* pointer / leading dimension not aligned as required */
+
+/* epilogue activation of tocvp_gemm_f32 */
+#define TOCVP_ACT_NONE 0
+#define TOCVP_ACT_RELU 1
+#define TOCVP_ACT_GELU 2 /* exact erf GELU (nn.TransformerEncoderLayer activation="gelu") */
+
+int tocvp_version(void);
+/* human-readable text for a TOCVP_E* code */
+const char* tocvp_strerror(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + rowvec[idx(row)][N]) + R[M,N]       (fp32 MFMA)
+ *
+ * Replaces every nn.Linear on the path: encoder_mlp (models/SAVi.py:115-120), to_q/to_k/to_v,
+ * GRU input/hidden projections and slot MLP (models/Blocks/attention.py:54-64,105-110),
+ * q/k/v/out projections and MLPs of TransformerBlock / AdaptedEncoderBlock
+ * (attention.py:167-175,296-300,355-359,428-432), mlp_in / mlp_out
+ * (models/Predictors/text_cond_OCVP.py:49-50), and the text encoder's linears
+ * (models/EncodersDecoders/text_encoders.py:44-69).
+ *
+ *   W is in nn.Linear layout (N rows of K).  lda/ldr/ldc are row strides in floats.
+ *   bias, R, rowvec may be NULL.  rowvec is (rv_mod, N): idx(row) = (row / rv_div) % rv_mod,
+ *   reversed (rv_mod-1-idx) when rv_flip != 0 -- this is the flipped learned temporal
+ *   positional encoding of models/Blocks/model_blocks.py:358-379.
+ *   Requirements: K % 4 == 0, lda % 4 == 0, A and W 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_gemm_f32(const float* A, int lda, const float* W, const float* bias,
+                   const float* R, int ldr,
+                   const float* rowvec, int rv_div, int rv_mod, int rv_flip,
+                   float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y[r,:] = LayerNorm(x[r,:] + add[r % add_rows,:]) * gamma + beta      (biased variance, eps)
+ * Replaces nn.LayerNorm at attention.py:49-51,361-362,427,435-436, SAVi.py:116 and
+ * text_encoders.py:63,65-68; `add` (may be NULL) fuses SoftPositionEmbed's addend
+ * (model_blocks.py:215-226).  D <= 1024, D % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_layernorm_f32(const float* x, const float* add, int add_rows, const float* gamma,
+                        const float* beta, float* y, int rows, int D, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention  O = softmax(Q K^T * scale [+ key-padding mask]) V        (fp32 MFMA,
+ * flash-style online softmax).  Replaces MetaAttention.attention/split_into_heads/merge_heads
+ * (attention.py:183-215) for MultiHeadSelfAttention (:245-265), MultiHeadCrossAttention
+ * (:303-319) and nn.MultiheadAttention inside nn.TransformerEncoderLayer (text_encoders.py:44-51).
+ *
+ *   Q:(B,Tq,H*dh) row stride ldq; K,V:(B,Tk,H*dh) row strides ldk, ldv; O row stride ldo.
+ *   Batch strides are Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo.  dh in {32, 64}.
+ *   key_len (int32, B entries, may be NULL): keys j >= key_len[b] are excluded
+ *   (src_key_padding_mask of text_encoders.py:104-105).
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                  float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
+                  const int32_t* key_len, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One slot-attention iteration over the feature grid (the north-star kernel), attention.py:99-103:
+ *     dots = q k^T * scale; attn = softmax_over_slots(dots) + eps;
+ *     updates = (attn / sum_N attn) v
+ * q:(B,Ks,D) contiguous; k,v:(B,N,D) with row stride ldkv (k and v may be the two halves of one
+ * fused (B,N,2D) projection); updates:(B,Ks,D).  attn_out (may be NULL): (B,Ks,N) = attn after
+ * "+eps" (SlotAttention.attention_masks side effect, attention.py:101).
+ * Ks <= 32, D == 128, N % 32 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes.
+ * Two launches: a location-streaming partial kernel (k/v read exactly once, coalesced) and a
+ * deterministic cross-chunk reduction + renormalisation.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_slot_attn_ws_bytes(int B, int N);
+int tocvp_slot_attn_iter_f32(const float* q, const float* k, const float* v, int ldkv,
+                             float* updates, float* attn_out, int B, int Ks, int N, int D,
+                             float scale, float eps, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * nn.GRUCell gate math (attention.py:105-108), gate order (r,z,n):
+ *   gi = W_ih x + b_ih, gh = W_hh h + b_hh  (both (rows,3D), from tocvp_gemm_f32)
+ *   out = (1-z)*n + z*h
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_gru_gates_f32(const float* gi, const float* gh, const float* h, float* out, int rows,
+                        int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SoftPositionEmbed addend (model_blocks.py:186-226, grid of model_utils.py:12-34):
+ *   pos[y,x,c] = sum_j grid[y,x,j] * w[c,j] + b[c],  grid = [gy, gx, 1-gy, 1-gx], g=linspace(-1,1)
+ * w:(C,4) (the 1x1 conv weight), out:(H,W,C).
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_pos_embed_f32(const float* w, const float* b, float* out, int H, int W, int C,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * First encoder layer: Conv2d(3->Cout, k5, p2) + ReLU reading the video tensor in place
+ * (encoders.py:130-154, layer 0).  x: image n at x + n*img_stride floats, planes (C,H,W)
+ * contiguous; w: nn.Conv2d layout (Cout,3,5,5); y: NHWC (nimg,H,W,Cout).  Cout == 32.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_conv5x5_in3_f32(const float* x, long long img_stride, const float* w, const float* bias,
+                          float* y, int nimg, int H, int W, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv2d(Cin->Cout, k5, p2) [+ReLU] as an implicit GEMM on fp32 MFMA, NHWC in / NHWC out.
+ * Replaces ConvBlock (model_blocks.py:49-108) in SimpleConvEncoder (encoders.py:130-154) and
+ * ConvDecoder (decoders.py:96-110).
+ *   wp: weights repacked as (25 taps, Cout, Cin) (tocvp_pack_conv_weights_f32).
+ *   Cin in {32,64,128}, Cout in {32,64}, H % 8 == 0, W % 32 == 0.
+ * Collapsed-input mode (in_mode = 1) implements the decoder's layer 0 analytically and feeds
+ * layer 1 without ever materialising SAVi.broadcast's (B*K,D,H,W) tensor (SAVi.py:264-275):
+ *   x_in[n,y,x,c] = relu(cpos[y,x,c] + S[n, cls(y,x), c]),
+ *   cpos = conv0(pos_embed) + bias0 (slot independent), S[n,cls,:] = tapsum[cls] * slot_n,
+ *   cls(y,x) in 5x5 border classes (which of the 25 taps fall inside the image).
+ *   In that mode x = cpos (H,W,Cin), aux = S (nimg,25,Cin).
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_pack_conv_weights_f32(const float* w, float* wp, int Cout, int Cin, int ksize,
+                                void* stream);
+int tocvp_conv5x5_f32(const float* x, const float* aux, int in_mode, const float* wp,
+                      const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
+                      int relu, void* stream);
+
+/* tap-sum matrices of the collapsed decoder layer 0:
+ *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of
+ *   w[co,ci,dy,dx];  w: (Cout,Cin,5,5), out: (25,Cout,Cin). */
+int tocvp_dec_tapsum_f32(const float* w, float* out, int Cout, int Cin, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder tail (SAVi.py:251-255 + decoders.py:111-118): Conv2d(Cin->4,k3,p1) per slot image,
+ * split RGB / alpha, softmax over the K slots, recon = sum_K rgb * mask.
+ *   x:(F*K,H,W,Cin) NHWC; w:(4,Cin,3,3) nn.Conv2d layout; bias:(4)
+ *   recons_imgs:(F,3,H,W)  recons:(F,K,3,H,W)  masks:(F,K,1,H,W)   (reference output layouts)
+ *   K <= 32, Cin == 64, H % 8 == 0, W % 16 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias, float* recons_imgs,
+                       float* recons, float* masks, int F, int K, int H, int W, int Cin,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Text-encoder front end (text_encoders.py:89-103): token + position embedding, LayerNorm
+ * (eps), zero the rows of padding tokens (id 0).  tokens: int64 (B,L); out: (B,L,D), D == 128.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_text_embed_f32(const int64_t* tokens, const float* tok_emb, const float* pos_emb,
+                         const float* gamma, const float* beta, float* out, int B, int L, int D,
+                         int vocab, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOCVP_H */

@@ -1,0 +1,233 @@
+"""
+Kernel-level parity: every C-ABI entry point of libtocvp.so against the CPU oracle / plain fp32
+torch-CPU math on the same seeded inputs.  Needs a real MI355X (pytest -m gpu).
+
+Tolerance: all kernels compute in fp32 (exact-fp32 MFMA fma chains), so the only differences to
+the CPU are summation order and libm (expf/erff/tanhf) -> 2e-5 relative to the output scale.
+"""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import slot_rollout_oracle as O
+from textocvp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _k():
+    from textocvp_amd import kernels
+    return kernels
+
+
+def rnd(name, shape, kind="normal", scale=1.0):
+    return synth.synth_tensor("ktest." + name, shape, kind, scale)
+
+
+def close(got, ref, tol=2e-5):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, f"max abs err {err:.3e} (scale {scale:.3g})"
+
+
+def test_library_loads_and_version():
+    k = _k()
+    assert k.lib().tocvp_version() == 100
+
+
+@pytest.mark.parametrize("M,N,K", [(30, 512, 512), (300, 1536, 512), (5000, 2048, 512),
+                                   (1000, 128, 32), (7, 36, 4), (129, 100, 68),
+                                   (20000, 256, 128), (210, 128, 2048)])
+def test_gemm_plain_bias_act(M, N, K):
+    k = _k()
+    x, w, b = rnd("gx", (M, K)), rnd("gw", (N, K), "uniform", K ** -0.5), rnd("gb", (N,))
+    ref = x @ w.t() + b
+    close(k.linear(x.to(DEV), w.to(DEV), b.to(DEV)), ref)
+    close(k.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU), torch.relu(ref))
+    close(k.linear(x.to(DEV), w.to(DEV), None, act=k.ACT_GELU), O.gelu(x @ w.t()))
+
+
+def test_gemm_residual_and_flipped_rowvec():
+    k = _k()
+    B, w_, Ks, D, E = 3, 4, 7, 128, 512
+    x = rnd("rx", (B, w_, Ks, D))
+    w, b = rnd("rw", (E, D), "uniform", D ** -0.5), rnd("rb", (E,))
+    pe = rnd("rpe", (w_, E))
+    res = rnd("rres", (B, w_, Ks, E))
+    ref = x @ w.t() + b + torch.flip(pe, dims=(0,))[None, :, None, :] + res
+    got = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=res.to(DEV), rowvec=pe.to(DEV),
+                   rv_div=Ks, rv_flip=True)
+    close(got, ref)
+    got2 = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), rowvec=pe.to(DEV), rv_div=Ks, rv_flip=False)
+    close(got2, x @ w.t() + b + pe[None, :, None, :])
+
+
+def test_gemm_rejects_bad_arguments():
+    k = _k()
+    x = torch.zeros(4, 6, device=DEV)          # K % 4 != 0
+    w = torch.zeros(8, 6, device=DEV)
+    with pytest.raises(k.TocvpError):
+        k.linear(x, w)
+    with pytest.raises(k.TocvpError):          # CPU tensors are refused: no CPU path
+        k.linear(torch.zeros(4, 8), torch.zeros(8, 8))
+
+
+@pytest.mark.parametrize("rows,D,eps,with_add", [(4096 * 2, 32, 1e-5, True), (61, 128, 1e-3, False),
+                                                 (300, 512, 1e-6, False), (5, 128, 1e-8, False)])
+def test_layernorm(rows, D, eps, with_add):
+    k = _k()
+    x, g, b = rnd("lx", (rows, D), "normal", 3.0), 1 + rnd("lg", (D,), "uniform", 0.3), rnd("lb", (D,))
+    add = rnd("la", (4096, D)) if with_add else None
+    xin = x + add.repeat(rows // 4096, 1) if with_add else x
+    ref = O.layer_norm(xin, g, b, eps)
+    got = k.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), eps, add=add.to(DEV) if with_add else None)
+    close(got, ref)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(2, 8, 300, 300, 64), (3, 8, 70, 20, 64), (2, 4, 7, 7, 32),
+                                          (2, 4, 30, 30, 32), (1, 8, 129, 33, 64)])
+def test_mha(B, H, Tq, Tk, dh):
+    k = _k()
+    E = H * dh
+    q, kk, v = rnd("aq", (B, Tq, E)), rnd("ak", (B, Tk, E)), rnd("av", (B, Tk, E))
+    ref = O.attention(q, kk, v, H, dh ** -0.5)
+    close(k.mha(q.to(DEV), kk.to(DEV), v.to(DEV), H, dh ** -0.5), ref)
+
+
+def test_mha_fused_qkv_views_and_key_lengths():
+    k = _k()
+    B, H, T, dh = 3, 4, 20, 32
+    E = H * dh
+    qkv = rnd("fqkv", (B, T, 3 * E))
+    lengths = torch.tensor([5, 12, 20], dtype=torch.int64)
+    key_pad = torch.arange(1, T + 1)[None, :] > lengths[:, None]
+    ref = O.attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, dh ** -0.5,
+                      key_mask=key_pad)
+    d = qkv.to(DEV)
+    got = k.mha(d[..., :E], d[..., E:2 * E], d[..., 2 * E:], H, dh ** -0.5,
+                key_len=lengths.to(torch.int32).to(DEV))
+    close(got, ref)
+
+
+@pytest.mark.parametrize("B,Ks,N", [(2, 7, 4096), (1, 30, 4096), (3, 24, 256), (40, 30, 4096)])
+def test_slot_attn_iter(B, Ks, N):
+    k = _k()
+    D = 128
+    q = rnd("sq", (B, Ks, D))
+    kv = rnd("skv", (B, N, 2 * D))
+    kk, v = kv[..., :D], kv[..., D:]
+    scale, eps = D ** -0.5, 1e-8
+    dots = (q @ kk.transpose(1, 2)) * scale
+    attn = torch.softmax(dots, dim=1) + eps
+    ref = (attn / attn.sum(-1, keepdim=True)) @ v
+    d = kv.to(DEV)
+    attn_out = torch.empty((B, Ks, N), device=DEV)
+    got = k.slot_attn_iter(q.to(DEV), d[..., :D], d[..., D:], scale, eps, attn_out=attn_out)
+    close(got, ref)
+    close(attn_out, attn, tol=1e-5)
+
+
+def test_gru_gates():
+    k = _k()
+    rows, D = 60, 128
+    x, h = rnd("gx2", (rows, D)), rnd("gh2", (rows, D))
+    wi, wh = rnd("gwi", (3 * D, D), "uniform", 0.1), rnd("gwh", (3 * D, D), "uniform", 0.1)
+    bi, bh = rnd("gbi", (3 * D,), "uniform", 0.1), rnd("gbh", (3 * D,), "uniform", 0.1)
+    ref = O.gru_cell(x, h, wi, wh, bi, bh)
+    cell = torch.nn.GRUCell(D, D)
+    with torch.no_grad():
+        cell.weight_ih.copy_(wi), cell.weight_hh.copy_(wh), cell.bias_ih.copy_(bi), cell.bias_hh.copy_(bh)
+        close(ref, cell(x, h), tol=1e-6)     # the oracle itself is torch's GRUCell
+    gi = k.linear(x.to(DEV), wi.to(DEV), bi.to(DEV))
+    gh = k.linear(h.to(DEV), wh.to(DEV), bh.to(DEV))
+    close(k.gru_gates(gi, gh, h.to(DEV)), ref)
+
+
+@pytest.mark.parametrize("C", [32, 128])
+def test_pos_embed(C):
+    k = _k()
+    w, b = rnd("pw", (C, 4, 1, 1)), rnd("pb", (C,))
+    ref = O.soft_pos_embed(w, b, (64, 64))
+    close(k.pos_embed(w.to(DEV), b.to(DEV), 64, 64), ref, tol=2e-6)
+
+
+def test_conv_in3():
+    k = _k()
+    vid = rnd("cvid", (2, 3, 3, 64, 64), "unit")          # (B, L, C, H, W): frames 1.. of a video
+    w, b = rnd("cw0", (32, 3, 5, 5), "uniform", 0.2), rnd("cb0", (32,), "uniform", 0.1)
+    x = vid[:, 1]                                           # strided view (B, 3, H, W)
+    ref = torch.relu(F.conv2d(x, w, b, padding=2)).permute(0, 2, 3, 1)
+    close(k.conv5x5_in3(vid.to(DEV)[:, 1], w.to(DEV), b.to(DEV)), ref)
+
+
+@pytest.mark.parametrize("Cin,Cout,n,relu", [(32, 32, 3, True), (64, 64, 5, True), (128, 64, 1, False),
+                                             (64, 64, 37, True)])
+def test_conv5x5(Cin, Cout, n, relu):
+    k = _k()
+    x = rnd("cx", (n, 64, 64, Cin))
+    w = rnd("cw", (Cout, Cin, 5, 5), "uniform", (25 * Cin) ** -0.5)
+    b = rnd("cb", (Cout,), "uniform", 0.1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=2)
+    ref = (torch.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    wp = k.pack_conv_weights(w.to(DEV))
+    close(wp, w.permute(2, 3, 0, 1).reshape(25, Cout, Cin), tol=0)
+    close(k.conv5x5(x.to(DEV), wp, b.to(DEV), relu=relu), ref)
+
+
+def test_decoder_layer0_collapse_matches_direct_conv():
+    """ relu(conv0(broadcast(s)+pos)) computed analytically == the reference's explicit path. """
+    k = _k()
+    n, D, C0 = 6, 128, 64
+    slots = rnd("dslots", (n, D))
+    pw, pb = rnd("dpw", (D, 4, 1, 1)), rnd("dpb", (D,))
+    w0 = rnd("dw0", (C0, D, 5, 5), "uniform", (25 * D) ** -0.5)
+    b0 = rnd("db0", (C0,), "uniform", 0.1)
+    w1 = rnd("dw1", (64, C0, 5, 5), "uniform", (25 * C0) ** -0.5)
+    b1 = rnd("db1", (64,), "uniform", 0.1)
+    pos = O.soft_pos_embed(pw, pb, (64, 64))
+    x0 = (slots[:, None, None, :] + pos[None]).permute(0, 3, 1, 2)
+    a0 = torch.relu(F.conv2d(x0, w0, b0, padding=2))
+    ref = torch.relu(F.conv2d(a0, w1, b1, padding=2)).permute(0, 2, 3, 1)
+
+    pos_d = k.pos_embed(pw.to(DEV), pb.to(DEV), 64, 64)
+    cpos = k.conv5x5(pos_d[None].contiguous(), k.pack_conv_weights(w0.to(DEV)), b0.to(DEV),
+                     relu=False)[0]
+    tapsum = k.dec_tapsum(w0.to(DEV))                                  # (25, C0, D)
+    S = k.linear(slots.to(DEV), tapsum.reshape(25 * C0, D)).reshape(n, 25, C0)
+    got = k.conv5x5_collapsed(cpos.contiguous(), S.contiguous(), k.pack_conv_weights(w1.to(DEV)),
+                              b1.to(DEV), relu=True)
+    close(got, ref, tol=3e-5)
+
+
+@pytest.mark.parametrize("Fr,K", [(2, 7), (1, 30)])
+def test_dec_tail(Fr, K):
+    k = _k()
+    x = rnd("tx", (Fr * K, 64, 64, 64))
+    w = rnd("tw", (4, 64, 3, 3), "uniform", 0.1)
+    b = rnd("tb", (4,), "uniform", 0.3)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).reshape(Fr, K, 4, 64, 64)
+    recons, alpha = y[:, :, :3], y[:, :, 3:]
+    masks = torch.softmax(alpha, dim=1)
+    imgs = (recons * masks).sum(1)
+    g_imgs, g_recons, g_masks = k.dec_tail(x.to(DEV), w.to(DEV), b.to(DEV), Fr, K)
+    close(g_recons, recons)
+    close(g_masks, masks, tol=1e-5)
+    close(g_imgs, imgs)
+
+
+def test_text_embed():
+    k = _k()
+    tokens, _ = synth.synth_captions(3, max_len=20, lengths=[5, 12, 20], seed=3)
+    te, pe = rnd("te", (50, 128)), rnd("tpe", (50, 128))
+    g, b = 1 + rnd("tg", (128,), "uniform", 0.2), rnd("tb2", (128,), "uniform", 0.1)
+    ref = O.layer_norm(te[tokens] + pe[:20][None], g, b, 1e-8) * (tokens != 0).unsqueeze(-1)
+    got = k.text_embed(tokens.to(DEV), te.to(DEV), pe.to(DEV), g.to(DEV), b.to(DEV), 1e-8)
+    close(got, ref)

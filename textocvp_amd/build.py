@@ -1,0 +1,58 @@
+"""
+Builds libtocvp.so (all hand-written HIP kernels + the C-ABI) in-tree for gfx950.
+
+    python -m textocvp_amd.build            # rebuild if any source is newer than the library
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container; the
+resulting .so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_DIR = os.path.join(PKG, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtocvp.so")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    lib_m = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return any(os.path.getmtime(d) > lib_m for d in deps)
+
+
+def build(force=False, verbose=False):
+    """ Compile every .hip under csrc/ into one shared library.  Returns the library path. """
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
+        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-comment",
+               f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

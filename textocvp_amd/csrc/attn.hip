@@ -1,0 +1,177 @@
+// Multi-head attention on fp32 MFMA (flash-style online softmax), sequences up to a few hundred
+// tokens: predictor self-attention (T <= 300, dh 64), text cross-attention (Tk <= 50),
+// SAVi transition (T = K slots, dh 32), text encoder (key-padding lengths, dh 32).
+//
+// gfx950 mapping
+//  * one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+//  * scores are computed TRANSPOSED, S^T = K Q^T (keys on accumulator rows, queries on lanes):
+//    the softmax statistics of a query are then an in-lane reduction over 16 registers plus ONE
+//    cross-half shuffle, and the exponentiated tile is directly the B operand (one fp32 per lane)
+//    of the next MFMA  O^T += V^T P^T  -- no LDS round trip, no transposition of P.
+//  * K/V are streamed in 32-key tiles through LDS (coalesced 16-byte global loads); Q is staged
+//    once.  Padded strides (dh+4) make every ds_read_b128 conflict-free.
+#include "common.h"
+
+namespace {
+
+struct MhaArgs {
+    const float* Q; int ldq;
+    const float* K; int ldk;
+    const float* V; int ldv;
+    float* O; int ldo;
+    int B, H, Tq, Tk;
+    float scale;
+    const int32_t* key_len;
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
+    constexpr int QS = DH + 4;          // padded row stride of Q / K tiles
+    constexpr int F4 = DH / 4;          // float4 per row
+    constexpr int ND = DH / 32;         // 32-wide blocks of the head dim
+    __shared__ __attribute__((aligned(16))) float lds[128 * QS + 32 * QS + 32 * DH];
+    float* Qs = lds;
+    float* Ks = lds + 128 * QS;
+    float* Vs = Ks + 32 * QS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128;
+
+    const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + head * DH;
+    const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
+    const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + head * DH;
+    float* Ob = p.O + (size_t)b * p.Tq * p.ldo + head * DH;
+
+    int kv_len = p.Tk;
+    if (p.key_len) {
+        kv_len = p.key_len[b];
+        kv_len = kv_len < 1 ? 1 : (kv_len > p.Tk ? p.Tk : kv_len);
+    }
+
+    // ---- stage the 128 query rows (zeros past Tq)
+    for (int i = t; i < 128 * F4; i += 256) {
+        const int r = i / F4, c = (i % F4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < p.Tq) v = *reinterpret_cast<const f32x4*>(Qb + (size_t)(q0 + r) * p.ldq + c);
+        *reinterpret_cast<f32x4*>(Qs + r * QS + c) = v;
+    }
+
+    const bool active = (q0 + wave * 32) < p.Tq;   // wave-uniform
+    float m_run = NEG_BIG, l_run = 0.f;
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+    const int nkb = (kv_len + 31) / 32;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();   // previous tile fully consumed (also orders the Q staging)
+        for (int i = t; i < 32 * F4; i += 256) {
+            const int r = i / F4, c = (i % F4) * 4;
+            const int key = kb * 32 + r;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < p.Tk) {
+                kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
+            }
+            *reinterpret_cast<f32x4*>(Ks + r * QS + c) = kv;
+            *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // S^T tile: rows = 32 keys, cols (lanes) = this wave's 32 queries
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* ka = Ks + l31 * QS + 4 * h;
+        const float* qa = Qs + (wave * 32 + l31) * QS + 4 * h;
+#pragma unroll
+        for (int j = 0; j < DH / 8; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ka + 8 * j);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(qa + 8 * j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = mfma32(a[u], bq[u], s);
+        }
+
+        // online softmax over keys: in-lane over 16 regs + the other lane half
+        float bm = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + acc_row(r, h);
+            s[r] = (key < kv_len) ? s[r] * p.scale : NEG_BIG;
+            bm = fmaxf(bm, s[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m_run, bm);
+        const float alpha = expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_new);
+            ps += s[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+        // O^T (dh x 32 queries) += V^T (dh x keys) * P^T (keys x queries); P^T is `s` as it stands
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* va = Vs + acc_row(r, h) * DH + l31;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) oacc[d] = mfma32(va[32 * d], s[r], oacc[d]);
+        }
+    }
+
+    // ---- epilogue: normalise, transpose through this wave's own Q rows in LDS, coalesced store
+    if (active) {
+        const float inv = 1.0f / l_run;
+        float* os = Qs + (wave * 32) * QS;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[l31 * QS + d * 32 + acc_row(r, h)] = oacc[d][r] * inv;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 32 * F4; i += 64) {
+            const int r = i / F4, c = (i % F4) * 4;
+            const int q = q0 + wave * 32 + r;
+            if (q < p.Tq)
+                *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + c) =
+                    *reinterpret_cast<const f32x4*>(os + r * QS + c);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V,
+                             int ldv, float* O, int ldo, int B, int H, int Tq, int Tk, int dh,
+                             float scale, const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Q && K && V && O);
+    TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq > 0 && Tk > 0);
+    TOCVP_CHECK_ARG(dh == 32 || dh == 64);
+    TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh);
+    TOCVP_CHECK_ARG(B <= 65535 && H <= 65535);
+    if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || !tocvp_aligned16(Q) ||
+        !tocvp_aligned16(K) || !tocvp_aligned16(V) || !tocvp_aligned16(O))
+        return TOCVP_EALIGN;
+    if (B == 0) return TOCVP_OK;
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len};
+    dim3 grid((Tq + 127) / 128, H, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dh == 64)
+        hipLaunchKernelGGL(mha_f32_kernel<64>, grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(mha_f32_kernel<32>, grid, dim3(256), 0, s, p);
+    return tocvp_launch_status();
+}

@@ -1,0 +1,48 @@
+// Shared device helpers for libtocvp (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tocvp.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TOCVP_CHECK_ARG(cond) \
+    do {                      \
+        if (!(cond)) return TOCVP_EINVAL; \
+    } while (0)
+
+static inline int tocvp_launch_status() {
+    return hipGetLastError() == hipSuccess ? TOCVP_OK : TOCVP_ELAUNCH;
+}
+
+static inline bool tocvp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact fp32 fma chain.
+//   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+//   D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), reg in [0,16).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register r for lane-half h (32x32 MFMA C/D layout)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// butterfly reductions over the 32 lanes of one wave half (lanes l and l^32 stay separate)
+__device__ __forceinline__ float half_max32(float v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum32(float v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,262 @@
+// Small HBM-bound row / elementwise kernels: LayerNorm (+fused positional addend), GRU gates,
+// SoftPositionEmbed table, text embedding front end, conv weight repacking, decoder tap sums.
+// One wave (64 lanes) per row with 16-byte loads and __shfl_xor butterflies; no LDS.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row cached in registers (D <= 1024)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ add, int add_rows,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        float* __restrict__ y, int rows, int D,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    const float* ar = add ? add + (size_t)(row % add_rows) * D : nullptr;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            if (ar) v[i] += *reinterpret_cast<const f32x4*>(ar + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum64(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const f32x4 d = v[i] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+            *reinterpret_cast<f32x4*>(y + (size_t)row * D + c) = (v[i] - mean) * rstd * g + b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRUCell gates
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gi,
+                                                        const float* __restrict__ gh,
+                                                        const float* __restrict__ h,
+                                                        float* __restrict__ out, int rows, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * D) return;
+    const long row = i / D;
+    const int d = (int)(i - row * D);
+    const float* gir = gi + row * 3 * D;
+    const float* ghr = gh + row * 3 * D;
+    const float r = sigmoidf_(gir[d] + ghr[d]);
+    const float z = sigmoidf_(gir[D + d] + ghr[D + d]);
+    const float n = tanhf(gir[2 * D + d] + r * ghr[2 * D + d]);
+    out[i] = (1.0f - z) * n + z * h[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// SoftPositionEmbed addend table (H, W, C)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pos_embed_kernel(const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ out, int H, int W, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)H * W * C) return;
+    const int c = (int)(i % C);
+    const int xx = (int)((i / C) % W);
+    const int yy = (int)(i / ((long)C * W));
+    // numpy.linspace(-1, 1, n) in float64, cast to fp32; "1 - g" is evaluated in fp32
+    const float gy = (H > 1) ? (float)(-1.0 + (double)yy * (2.0 / (double)(H - 1))) : -1.0f;
+    const float gx = (W > 1) ? (float)(-1.0 + (double)xx * (2.0 / (double)(W - 1))) : -1.0f;
+    const float* wc = w + (size_t)c * 4;
+    float v = gy * wc[0];
+    v = fmaf(gx, wc[1], v);
+    v = fmaf(1.0f - gy, wc[2], v);
+    v = fmaf(1.0f - gx, wc[3], v);
+    out[i] = v + b[c];
+}
+
+// ------------------------------------------------------------------------------------------
+// text front end: (tok_emb[id] + pos_emb[j]) -> LayerNorm -> zero padding rows
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ tokens,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         float* __restrict__ out, int rows, int L,
+                                                         int D, int vocab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    long id = tokens[row];
+    const bool pad = (id == 0);
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const int j = row % L;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = 0.f;
+        if (c < D) {
+            v[i] = tok_emb[(size_t)id * D + c] + pos_emb[(size_t)j * D + c];
+            s += v[i];
+        }
+    }
+    const float mean = wave_sum64(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < D) q += (v[i] - mean) * (v[i] - mean);
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            out[(size_t)row * D + c] = pad ? 0.f : o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv weight repack (Cout, Cin, k, k) -> (k*k, Cout, Cin)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w,
+                                                        float* __restrict__ wp, int Cout, int Cin,
+                                                        int kk) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)kk * Cout * Cin) return;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tap = (int)(i / ((long)Cin * Cout));
+    wp[i] = w[((size_t)co * Cin + ci) * kk + tap];
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder layer-0 tap sums: out[(cy*5+cx), co, ci] = sum of the taps that stay inside the image
+// for an output pixel of border class (cy, cx):  class 0/1 = first/second row (or column),
+// 2 = interior, 3/4 = second-to-last/last.  Tap dy in [-2,2] is valid iff the input row y+dy
+// exists: class 0 -> dy >= 0, class 1 -> dy >= -1, class 3 -> dy <= 1, class 4 -> dy <= 0.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void class_range(int cls, int& lo, int& hi) {
+    lo = (cls == 0) ? 2 : (cls == 1) ? 1 : 0;      // tap index = d + 2
+    hi = (cls == 4) ? 2 : (cls == 3) ? 3 : 4;
+}
+
+__global__ __launch_bounds__(256) void dec_tapsum_kernel(const float* __restrict__ w,
+                                                         float* __restrict__ out, int Cout, int Cin) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)25 * Cout * Cin) return;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int cls = (int)(i / ((long)Cin * Cout));
+    int ylo, yhi, xlo, xhi;
+    class_range(cls / 5, ylo, yhi);
+    class_range(cls % 5, xlo, xhi);
+    const float* wk = w + ((size_t)co * Cin + ci) * 25;
+    float s = 0.f;
+    for (int ty = ylo; ty <= yhi; ++ty)
+        for (int tx = xlo; tx <= xhi; ++tx) s += wk[ty * 5 + tx];
+    out[i] = s;
+}
+
+inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int tocvp_version(void) { return TOCVP_VERSION; }
+
+extern "C" const char* tocvp_strerror(int code) {
+    switch (code) {
+        case TOCVP_OK: return "ok";
+        case TOCVP_EINVAL: return "invalid argument";
+        case TOCVP_ELAUNCH: return "kernel launch failed";
+        case TOCVP_EALIGN: return "pointer or leading dimension not 16-byte aligned";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int tocvp_layernorm_f32(const float* x, const float* add, int add_rows,
+                                   const float* gamma, const float* beta, float* y, int rows, int D,
+                                   float eps, void* stream) {
+    TOCVP_CHECK_ARG(x && gamma && beta && y);
+    TOCVP_CHECK_ARG(rows >= 0 && D > 0 && D <= 1024 && (D & 3) == 0);
+    TOCVP_CHECK_ARG(add == nullptr || add_rows > 0);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) ||
+        !tocvp_aligned16(beta) || (add && !tocvp_aligned16(add)))
+        return TOCVP_EALIGN;
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, add, add_rows, gamma, beta, y, rows, D,
+                       eps);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_gru_gates_f32(const float* gi, const float* gh, const float* h, float* out,
+                                   int rows, int D, void* stream) {
+    TOCVP_CHECK_ARG(gi && gh && h && out && rows >= 0 && D > 0);
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3(blocks_for((long)rows * D, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), gi, gh, h, out, rows, D);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_pos_embed_f32(const float* w, const float* b, float* out, int H, int W, int C,
+                                   void* stream) {
+    TOCVP_CHECK_ARG(w && b && out && H > 0 && W > 0 && C > 0);
+    hipLaunchKernelGGL(pos_embed_kernel, dim3(blocks_for((long)H * W * C, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, b, out, H, W, C);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_text_embed_f32(const int64_t* tokens, const float* tok_emb,
+                                    const float* pos_emb, const float* gamma, const float* beta,
+                                    float* out, int B, int L, int D, int vocab, float eps,
+                                    void* stream) {
+    TOCVP_CHECK_ARG(tokens && tok_emb && pos_emb && gamma && beta && out);
+    TOCVP_CHECK_ARG(B >= 0 && L > 0 && D > 0 && D <= 256 && vocab > 0);
+    if (B == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(text_embed_kernel, dim3(blocks_for((long)B * L, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tokens, tok_emb, pos_emb, gamma, beta, out,
+                       B * L, L, D, vocab, eps);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_pack_conv_weights_f32(const float* w, float* wp, int Cout, int Cin, int ksize,
+                                           void* stream) {
+    TOCVP_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && ksize > 0);
+    const int kk = ksize * ksize;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks_for((long)kk * Cout * Cin, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, wp, Cout, Cin, kk);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_tapsum_f32(const float* w, float* out, int Cout, int Cin, void* stream) {
+    TOCVP_CHECK_ARG(w && out && Cout > 0 && Cin > 0);
+    hipLaunchKernelGGL(dec_tapsum_kernel, dim3(blocks_for((long)25 * Cout * Cin, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, out, Cout, Cin);
+    return tocvp_launch_status();
+}

@@ -1,0 +1,307 @@
+"""
+ctypes binding of libtocvp.so (include/tocvp.h) + thin tensor-level wrappers.
+
+PyTorch is used only for device memory and the current HIP stream; every computation on the hot
+path is one of the hand-written HIP kernels behind the C-ABI.  There is NO fallback: if the
+library is missing or a call fails, this module raises.
+"""
+
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_c_float_p = ctypes.c_void_p
+_LIB = None
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+_SIGNATURES = {
+    "tocvp_version": (ctypes.c_int, []),
+    "tocvp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "tocvp_gemm_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_layernorm_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
+    "tocvp_mha_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_slot_attn_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "tocvp_slot_attn_iter_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_gru_gates_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_pos_embed_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_conv5x5_in3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_pack_conv_weights_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_conv5x5_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_dec_tapsum_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_dec_tail_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_text_embed_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class TocvpError(RuntimeError):
+    pass
+
+
+def lib():
+    """ Load libtocvp.so once; raise loudly when it is missing (no CPU / torch fallback). """
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise TocvpError(
+                f"{path} not found: build the HIP extension first "
+                f"(python -m textocvp_amd.build, or __graft_entry__.build())")
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def _check(code, what):
+    if code != 0:
+        msg = lib().tocvp_strerror(code).decode()
+        raise TocvpError(f"{what} failed: {msg} ({code})")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_f32(t, name):
+    if t.device.type != "cuda":
+        raise TocvpError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TocvpError(f"{name} must be float32 (got {t.dtype})")
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# tensor-level wrappers
+# --------------------------------------------------------------------------------------------
+
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_div=1, rv_flip=False,
+           out=None):
+    """
+    y = act(x W^T + bias + rowvec[idx(row)]) + residual over the last axis of ``x``.
+    x: (..., K) contiguous, weight: (N, K) in nn.Linear layout.
+    """
+    _dev_f32(x, "x"), _dev_f32(weight, "weight")
+    K = x.shape[-1]
+    N = weight.shape[0]
+    assert weight.shape[1] == K, (weight.shape, x.shape)
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        assert r2.shape[0] == M and r2.is_contiguous()
+    rv_mod = 1
+    if rowvec is not None:
+        assert rowvec.is_contiguous() and rowvec.shape[-1] == N
+        rv_mod = rowvec.numel() // N
+    _check(lib().tocvp_gemm_f32(_ptr(x2), K, _ptr(w), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
+                                int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out), N, M, N, K,
+                                int(act), _stream()), "tocvp_gemm_f32")
+    return out.reshape(*x.shape[:-1], N)
+
+
+def layer_norm(x, gamma, beta, eps, add=None):
+    """ LayerNorm over the last axis; ``add`` (R, D) is added row-periodically before the norm. """
+    _dev_f32(x, "x")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    add_rows = 0
+    if add is not None:
+        assert add.is_contiguous() and add.shape[-1] == D
+        add_rows = add.numel() // D
+    _check(lib().tocvp_layernorm_f32(_ptr(x2), _ptr(add), add_rows, _ptr(gamma), _ptr(beta),
+                                     _ptr(y), rows, D, float(eps), _stream()),
+           "tocvp_layernorm_f32")
+    return y.reshape(x.shape)
+
+
+def mha(q, k, v, heads, scale, key_len=None):
+    """
+    q: (B, Tq, E) view with unit last stride (may be a column slice of a fused projection);
+    k, v: (B, Tk, E) likewise.  Returns (B, Tq, E) contiguous.
+    """
+    B, Tq, E = q.shape
+    Tk = k.shape[1]
+    dh = E // heads
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _dev_f32(t, name)
+        assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), (name, t.stride())
+    o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
+    if key_len is not None:
+        assert key_len.dtype == torch.int32 and key_len.is_cuda and key_len.numel() == B
+    _check(lib().tocvp_mha_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1),
+                               _ptr(o), E, B, heads, Tq, Tk, dh, float(scale), _ptr(key_len),
+                               _stream()), "tocvp_mha_f32")
+    return o
+
+
+def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
+    """ q (B, Ks, D); k, v (B, N, D) views with row stride ldkv -> updates (B, Ks, D). """
+    B, Ks, D = q.shape
+    N = k.shape[1]
+    _dev_f32(q, "q"), _dev_f32(k, "k"), _dev_f32(v, "v")
+    assert q.is_contiguous()
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    assert k.stride(0) == N * k.stride(1) and v.stride(0) == N * v.stride(1)
+    need = lib().tocvp_slot_attn_ws_bytes(B, N)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, device=q.device, dtype=torch.float32)
+    upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
+    _check(lib().tocvp_slot_attn_iter_f32(_ptr(q), _ptr(k), _ptr(v), k.stride(1), _ptr(upd),
+                                          _ptr(attn_out), B, Ks, N, D, float(scale), float(eps),
+                                          _ptr(ws), ws.numel() * 4, _stream()),
+           "tocvp_slot_attn_iter_f32")
+    return upd
+
+
+def gru_gates(gi, gh, h):
+    rows, D = h.reshape(-1, h.shape[-1]).shape
+    out = torch.empty_like(h)
+    _check(lib().tocvp_gru_gates_f32(_ptr(gi), _ptr(gh), _ptr(h), _ptr(out), rows, D, _stream()),
+           "tocvp_gru_gates_f32")
+    return out
+
+
+def pos_embed(proj_weight, proj_bias, H, W):
+    """ SoftPositionEmbed addend (H, W, C) from the 1x1-conv parameters (C,4,1,1), (C,). """
+    C = proj_weight.shape[0]
+    w = proj_weight.reshape(C, 4).contiguous()
+    out = torch.empty((H, W, C), device=w.device, dtype=torch.float32)
+    _check(lib().tocvp_pos_embed_f32(_ptr(w), _ptr(proj_bias), _ptr(out), H, W, C, _stream()),
+           "tocvp_pos_embed_f32")
+    return out
+
+
+def pack_conv_weights(w):
+    """ (Cout, Cin, k, k) -> (k*k, Cout, Cin) """
+    Cout, Cin, k, _ = w.shape
+    w = w.contiguous()
+    out = torch.empty((k * k, Cout, Cin), device=w.device, dtype=torch.float32)
+    _check(lib().tocvp_pack_conv_weights_f32(_ptr(w), _ptr(out), Cout, Cin, k, _stream()),
+           "tocvp_pack_conv_weights_f32")
+    return out
+
+
+def conv5x5_in3(x, w, bias):
+    """ x: (n, 3, H, W) view whose images are contiguous planes; returns NHWC (n, H, W, Cout). """
+    n, C, H, W = x.shape
+    assert C == 3 and x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W
+    Cout = w.shape[0]
+    y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
+    _check(lib().tocvp_conv5x5_in3_f32(_ptr(x), x.stride(0) if n > 1 else 3 * H * W,
+                                       _ptr(w.contiguous()), _ptr(bias), _ptr(y), n, H, W, Cout,
+                                       _stream()), "tocvp_conv5x5_in3_f32")
+    return y
+
+
+def conv5x5(x, wp, bias, relu=True, out=None):
+    """ NHWC (n, H, W, Cin) -> (n, H, W, Cout) with packed weights (25, Cout, Cin). """
+    n, H, W, Cin = x.shape
+    Cout = wp.shape[1]
+    assert x.is_contiguous() and wp.shape[0] == 25 and wp.shape[2] == Cin
+    if out is None:
+        out = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
+    _check(lib().tocvp_conv5x5_f32(_ptr(x), None, 0, _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
+                                   Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
+    return out
+
+
+def conv5x5_collapsed(cpos, S, wp, bias, relu=True, out=None):
+    """
+    Decoder layer 1 fed by the analytically collapsed layer 0:
+    cpos (H, W, Cin) = conv0(pos)+bias0, S (n, 25, Cin) per-slot tap sums -> (n, H, W, Cout).
+    """
+    H, W, Cin = cpos.shape
+    n = S.shape[0]
+    Cout = wp.shape[1]
+    assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
+    if out is None:
+        out = torch.empty((n, H, W, Cout), device=cpos.device, dtype=torch.float32)
+    _check(lib().tocvp_conv5x5_f32(_ptr(cpos), _ptr(S), 1, _ptr(wp), _ptr(bias), _ptr(out), n, H, W,
+                                   Cin, Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
+    return out
+
+
+def dec_tapsum(w):
+    """ (Cout, Cin, 5, 5) -> (25, Cout, Cin) border-class tap sums """
+    Cout, Cin = w.shape[:2]
+    out = torch.empty((25, Cout, Cin), device=w.device, dtype=torch.float32)
+    _check(lib().tocvp_dec_tapsum_f32(_ptr(w.contiguous()), _ptr(out), Cout, Cin, _stream()),
+           "tocvp_dec_tapsum_f32")
+    return out
+
+
+def dec_tail(x, w, bias, F, K):
+    """ x: (F*K, H, W, Cin) NHWC -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W) """
+    n, H, W, Cin = x.shape
+    assert n == F * K and x.is_contiguous()
+    dev = x.device
+    imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
+    recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
+    masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
+    _check(lib().tocvp_dec_tail_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs),
+                                    _ptr(recons), _ptr(masks), F, K, H, W, Cin, _stream()),
+           "tocvp_dec_tail_f32")
+    return imgs, recons, masks
+
+
+def text_embed(tokens, tok_emb, pos_emb, gamma, beta, eps):
+    B, L = tokens.shape
+    D = tok_emb.shape[1]
+    assert tokens.dtype == torch.int64 and tokens.is_cuda and tokens.is_contiguous()
+    out = torch.empty((B, L, D), device=tokens.device, dtype=torch.float32)
+    _check(lib().tocvp_text_embed_f32(_ptr(tokens), _ptr(tok_emb), _ptr(pos_emb), _ptr(gamma),
+                                      _ptr(beta), _ptr(out), B, L, D, tok_emb.shape[0], float(eps),
+                                      _stream()), "tocvp_text_embed_f32")
+    return out
