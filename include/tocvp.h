@@ -95,7 +95,7 @@ int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float*
  * q:(B,Ks,D) contiguous; k,v:(B,N,D) with row stride ldkv (k and v may be the two halves of one
  * fused (B,N,2D) projection); updates:(B,Ks,D).  attn_out (may be NULL): (B,Ks,N) = attn after
  * "+eps" (SlotAttention.attention_masks side effect, attention.py:101).
- * Ks <= 32, D == 128, N % 32 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes.
+ * Ks <= 32, D == 128, N % 64 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes.
  * Two launches: a location-streaming partial kernel (k/v read exactly once, coalesced) and a
  * deterministic cross-chunk reduction + renormalisation.
  * ------------------------------------------------------------------------------------------- */
@@ -170,6 +170,14 @@ int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias, float*
 int tocvp_text_embed_f32(const int64_t* tokens, const float* tok_emb, const float* pos_emb,
                          const float* gamma, const float* beta, float* out, int B, int L, int D,
                          int vocab, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LearnedRandom slot initialiser (models/Blocks/initializers.py:87-94):
+ *   out[r,:] = mu + sigma * noise[r,:],  mu/sigma: (D), noise/out: (rows, D).
+ * The Gaussian draw itself stays on the host CPU generator for RNG parity with the reference.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_slot_init_f32(const float* mu, const float* sigma, const float* noise, float* out,
+                        int rows, int D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""
+CPU checks of the drop-in boundary: checkpoint layout (state_dict keys + shapes vs the manifest
+captured from the reference), factories, error behaviour, C-ABI symbol table.  No GPU compute.
+"""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from textocvp_amd import build as tbuild
+from textocvp_amd import synth
+from textocvp_amd.setup_model import (default_exp_params, load_checkpoint, setup_model,
+                                      setup_predictor)
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_state_dict_layout_matches_reference(manifest):
+    exp = default_exp_params(num_slots=30, num_preds=19)
+    savi = setup_model(exp["model"])
+    pred = setup_predictor(exp)
+    got_s = {k: list(v.shape) for k, v in savi.state_dict().items()}
+    got_p = {k: list(v.shape) for k, v in pred.state_dict().items()}
+    assert got_s == manifest["SAVi"]
+    assert got_p == manifest["PredictorWrapper"]
+    assert len(got_s) == 62 and len(got_p) == 253
+    # attributes the reference evaluator reads (05_evaluate_predictor.py:71-72, baseEvaluator.py:154)
+    assert savi.num_slots == 30 and savi.slot_dim == 128
+    assert hasattr(pred, "predictor") and next(iter(got_p)).startswith("predictor")
+
+
+def test_factory_does_not_consume_callers_config():
+    exp = default_exp_params()
+    setup_model(exp["model"])
+    setup_model(exp["model"])        # the reference pops keys; a second build must still work here
+    assert "num_channels" in exp["model"]["model_params"]["encoder"]["encoder_params"]
+
+
+def test_checkpoint_roundtrip_and_prefix_shim(tmp_path):
+    exp = default_exp_params(num_slots=7, num_preds=4)
+    savi = setup_model(exp["model"])
+    synth.fill_module_(savi, prefix="savi.")
+    path = tmp_path / "checkpoint_epoch_final.pth"
+    torch.save({"epoch": 3, "model_state_dict": savi.state_dict()}, path)
+    other = load_checkpoint(str(path), setup_model(exp["model"]), only_model=True)
+    for (k, a), (_, b) in zip(savi.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+    # bare predictor checkpoint (keys without 'predictor.') loads into the wrapper
+    pred = setup_predictor(exp)
+    bare = {k[len("predictor."):]: v for k, v in pred.state_dict().items()}
+    p2 = tmp_path / "pred.pth"
+    torch.save({"epoch": 0, "model_state_dict": bare}, p2)
+    load_checkpoint(str(p2), setup_predictor(exp), only_model=True)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(str(tmp_path / "nope.pth"), savi)
+
+
+def test_error_behaviour_matches_reference():
+    exp = default_exp_params(num_slots=7, num_preds=4)
+    savi = setup_model(exp["model"])
+    with pytest.raises(NameError):
+        savi(mode="nonsense")
+    pred = setup_predictor(exp)
+    with torch.no_grad(), pytest.raises(KeyError):
+        pred(torch.zeros(1, 5, 7, 128))                       # no caption_tokens
+    with pytest.raises(ValueError):
+        from textocvp_amd.models.Blocks.initializers import get_initializer
+        get_initializer("bogus", 128, 7)
+
+
+def test_product_refuses_cpu_tensors():
+    """ no CPU fallback: a CPU forward must fail loudly, never silently compute """
+    from textocvp_amd import kernels
+    exp = default_exp_params(num_slots=7, num_preds=4)
+    savi = setup_model(exp["model"]).eval()
+    with torch.no_grad(), pytest.raises((kernels.TocvpError, RuntimeError)):
+        savi(mode="decode", slots=torch.zeros(1, 7, 128))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """ the library loads and exports exactly the entry points include/tocvp.h declares """
+    from textocvp_amd import kernels
+    path = tbuild.build()
+    handle = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "tocvp.h")).read()
+    declared = set(re.findall(r"\b(tocvp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in tocvp.h but not exported"
+    assert declared == set(kernels.EXPORTED_SYMBOLS)
+    handle.tocvp_version.restype = ctypes.c_int
+    assert handle.tocvp_version() == 100
+
+
+def test_product_never_imports_the_oracle():
+    """ oracle/ is test infrastructure: nothing under textocvp_amd/ may reference it """
+    pkg = os.path.join(ROOT, "textocvp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f == "synth.py", os.path.join(dirpath, f)

@@ -1,0 +1,198 @@
+"""
+Module-level and end-to-end parity of the MI355X path (textocvp_amd.models through the C-ABI)
+against (a) the golden vectors produced by the reference itself and (b) the CPU oracle on the same
+seeded inputs / weights.  Needs a real MI355X (pytest -m gpu).
+
+Tolerance = the north-star bar: 1e-4 absolute on slots and rendered pixels, identical
+argmax_K(masks) maps (slot-index permutation).  Unit fixtures use 5e-5.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_abs
+from oracle import slot_rollout_oracle as O
+from textocvp_amd import synth
+from textocvp_amd.evaluator import forward_eval
+from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(num_slots, num_preds):
+    exp = default_exp_params(num_slots=num_slots, num_context=1, num_preds=num_preds)
+    savi = setup_model(exp["model"]).eval()
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(savi, prefix="savi.")
+    synth.fill_module_(pred, prefix="pred.")
+    return savi.to(DEV), pred.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def k7():
+    return build(7, 4)
+
+
+@pytest.fixture(scope="module")
+def k30():
+    return build(30, 19)
+
+
+def gpu(t):
+    return t.to(DEV)
+
+
+@torch.no_grad()
+def test_units_k7_against_reference_goldens(k7):
+    savi, pred = k7
+    core = pred.predictor
+    g = load_golden("units_k7.npz")
+    B, K, D = 2, 7, 128
+
+    imgs = synth.synth_tensor("unit.imgs", (B, 3, 64, 64), "unit")
+    assert max_abs(savi.encode(gpu(imgs))[:, ::16].cpu(), g["encoder_feats_sub16"]) < 5e-5
+
+    sa_in = synth.synth_tensor("unit.sa_feats", (B, 4096, D), "normal")
+    slots0 = synth.synth_tensor("unit.sa_slots", (B, K, D), "normal")
+    savi.slot_attention.store_attention_masks = True
+    s0 = savi.slot_attention(gpu(sa_in), gpu(slots0), step=0)
+    assert max_abs(s0.cpu(), g["sa_step0"]) < 1e-4
+    attn = savi.slot_attention.get_attention_masks()
+    assert max_abs(attn[:, :, ::16].cpu(), g["sa_step0_attn_sub16"]) < 1e-5
+    savi.slot_attention.store_attention_masks = False
+    s1 = savi.slot_attention(gpu(sa_in), gpu(slots0), step=1)
+    assert max_abs(s1.cpu(), g["sa_step1"]) < 5e-5
+
+    assert max_abs(savi.transition_module(gpu(slots0)).cpu(), g["transition"]) < 2e-5
+
+    tokens, lengths = torch.from_numpy(g["text_tokens"]), torch.from_numpy(g["text_lengths"])
+    text = core.text_encoder(text=gpu(tokens), text_length=gpu(lengths))
+    assert max_abs(text.cpu(), g["text_emb"]) < 5e-5
+
+    text_ref = gpu(torch.from_numpy(g["text_emb"]))
+    x = synth.synth_tensor("unit.block_x", (3, 2 * K, 512), "normal")
+    assert max_abs(core.predictor[0](gpu(x), text_ref).cpu(), g["block0"]) < 1e-4
+
+    win1 = synth.synth_tensor("unit.win1", (3, 1, K, D), "normal")
+    win10 = synth.synth_tensor("unit.win10", (3, 10, K, D), "normal")
+    assert max_abs(core(slots=gpu(win1), text_embeddings=text_ref).cpu(), g["pred_step_w1"]) < 1e-4
+    assert max_abs(core(slots=gpu(win10), text_embeddings=text_ref).cpu(), g["pred_step_w10"]) < 1e-4
+
+    dslots = synth.synth_tensor("unit.dec_slots", (2, K, D), "normal")
+    out = savi(mode="decode", slots=gpu(dslots))
+    assert out["recons"].shape == (2, K, 3, 64, 64) and out["masks"].shape == (2, K, 1, 64, 64)
+    assert max_abs(out["recons_imgs"].cpu(), g["dec7_recons_imgs"]) < 5e-5
+    assert max_abs(out["recons"][..., ::4, ::4].cpu(), g["dec7_recons_sub4"]) < 5e-5
+    assert max_abs(out["masks"][..., ::4, ::4].cpu(), g["dec7_masks_sub4"]) < 2e-5
+
+
+@torch.no_grad()
+def test_decoder_k30_against_reference_golden(k30):
+    savi, _ = k30
+    g = load_golden("units_k30.npz")
+    dslots = synth.synth_tensor("unit.dec_slots30", (2, 30, 128), "normal")
+    out = savi(mode="decode", slots=gpu(dslots))
+    assert max_abs(out["recons_imgs"].cpu(), g["dec30_recons_imgs"]) < 5e-5
+    assert max_abs(out["recons"][..., ::8, ::8].cpu(), g["dec30_recons_sub8"]) < 5e-5
+    assert max_abs(out["masks"][..., ::8, ::8].cpu(), g["dec30_masks_sub8"]) < 2e-5
+
+
+@torch.no_grad()
+def test_e2e_config1_against_reference_golden(k7):
+    """ config 1: K=7, B=2, 1 seed + 4 preds, ragged captions padded per batch """
+    savi, pred = k7
+    g = load_golden("e2e_c1.npz")
+    videos = synth.synth_videos(2, 5, seed=0)
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    out = forward_eval(savi, pred, gpu(videos), 1, 4, caption_tokens=gpu(tokens),
+                       caption_lengths=gpu(lengths), init_noise=noise)
+    assert out["slot_history"].shape == (2, 5, 7, 128)
+    assert max_abs(out["slot_history"].cpu(), g["slot_history"]) < 1e-4
+    assert max_abs(out["pred_slots"].cpu(), g["pred_slots"]) < 1e-4
+    assert max_abs(out["pred_imgs"].cpu(), g["pred_imgs"]) < 1e-4
+    am = out["masks"].argmax(dim=1).to(torch.uint8).cpu().numpy()
+    assert np.array_equal(am, g["masks_argmax"]), "slot-index permutation differs"
+
+
+@torch.no_grad()
+def test_e2e_config2_against_reference_golden(k30):
+    """ config 2 (north star): K=30, B=1, 1 seed + 19 preds """
+    savi, pred = k30
+    g = load_golden("e2e_c2.npz")
+    videos = synth.synth_videos(1, 20, seed=0)
+    tokens, lengths = synth.synth_captions(1, max_len=12, seed=0)
+    noise = synth.synth_noise(1, 30, 128, seed=1)
+    out = forward_eval(savi, pred, gpu(videos), 1, 19, caption_tokens=gpu(tokens),
+                       caption_lengths=gpu(lengths), init_noise=noise)
+    assert max_abs(out["slot_history"].cpu(), g["slot_history"]) < 1e-4
+    assert max_abs(out["pred_slots"].cpu(), g["pred_slots"]) < 1e-4
+    assert max_abs(out["pred_imgs"][..., ::2, ::2].cpu(), g["pred_imgs_sub2"]) < 1e-4
+    am = out["masks"].argmax(dim=1)[..., ::2, ::2].to(torch.uint8).cpu().numpy()
+    assert np.array_equal(am, g["masks_argmax_sub2"]), "slot-index permutation differs"
+
+
+@torch.no_grad()
+def test_e2e_against_oracle_fresh_inputs(k7):
+    """ seeds not covered by the fixtures, B=3 with three different caption lengths """
+    savi, pred = k7
+    ssd = {k: v.cpu() for k, v in savi.state_dict().items()}
+    psd = {k: v.cpu() for k, v in pred.state_dict().items()}
+    videos = synth.synth_videos(3, 5, seed=11)
+    tokens, lengths = synth.synth_captions(3, max_len=15, lengths=[4, 15, 9], seed=5)
+    noise = synth.synth_noise(3, 7, 128, seed=12)
+    hist, preds, imgs, masks = O.forward_eval(ssd, psd, videos, tokens, lengths, noise, 1, 4)
+    out = forward_eval(savi, pred, gpu(videos), 1, 4, caption_tokens=gpu(tokens),
+                       caption_lengths=gpu(lengths), init_noise=noise)
+    assert max_abs(out["slot_history"].cpu(), hist) < 1e-4
+    assert max_abs(out["pred_slots"].cpu(), preds) < 1e-4
+    assert max_abs(out["pred_imgs"].cpu(), imgs) < 1e-4
+    assert torch.equal(out["masks"].argmax(dim=1).cpu(), masks.argmax(dim=1))
+
+
+@torch.no_grad()
+def test_full_size_properties(k30):
+    """
+    Size-independent properties at the bench shape (K=30, 1+19, B=4):
+      * samples do not interact: a batch of 4 equals four batch-of-1 runs (same caption length);
+      * masks are a partition of unity over slots and rendered frames are their convex blend;
+      * decode=True in forward_decomp equals decode() of the returned slot_history.
+    """
+    savi, pred = k30
+    B = 4
+    videos = gpu(synth.synth_videos(B, 20, seed=21))
+    tokens, lengths = synth.synth_captions(B, max_len=12, seed=21)
+    noise = synth.synth_noise(B, 30, 128, seed=22)
+    out = forward_eval(savi, pred, videos, 1, 19, caption_tokens=gpu(tokens),
+                       caption_lengths=gpu(lengths), init_noise=noise)
+    for b in (0, 3):
+        one = forward_eval(savi, pred, videos[b:b + 1], 1, 19, caption_tokens=gpu(tokens[b:b + 1]),
+                           caption_lengths=gpu(lengths[b:b + 1]), init_noise=noise[b:b + 1])
+        assert max_abs(one["pred_slots"].cpu(), out["pred_slots"][b:b + 1].cpu()) < 2e-5
+        assert max_abs(one["pred_imgs"].cpu(), out["pred_imgs"][b:b + 1].cpu()) < 2e-5
+    assert max_abs(out["masks"].sum(dim=1).cpu(), torch.ones(B * 19, 1, 64, 64)) < 1e-5
+    assert torch.isfinite(out["pred_slots"]).all() and torch.isfinite(out["pred_imgs"]).all()
+
+    dec = savi(mode="decomp", x=videos[:1], num_imgs=3, decode=True, init_noise=noise[:1])
+    assert dec["recons_imgs"].shape == (1, 3, 3, 64, 64)
+    assert dec["recons_objs"].shape == (1, 3, 30, 3, 64, 64) and dec["masks"].shape == (1, 3, 30, 1, 64, 64)
+    again = savi(mode="decode", slots=dec["slot_history"].reshape(3, 30, 128))
+    assert max_abs(again["recons_imgs"].cpu(), dec["recons_imgs"][0].cpu()) == 0.0
+    nodec = savi(mode="decomp", x=videos[:1], num_imgs=3, decode=False, init_noise=noise[:1])
+    assert nodec["recons_imgs"].shape == (0, 3)
+    assert max_abs(nodec["slot_history"].cpu(), dec["slot_history"].cpu()) == 0.0
+
+
+@torch.no_grad()
+def test_slot_permutation_equivariance(k7):
+    """ permuting the initial slots permutes slot_history identically (slot-index bookkeeping) """
+    savi, _ = k7
+    videos = gpu(synth.synth_videos(1, 3, seed=31))
+    noise = synth.synth_noise(1, 7, 128, seed=32)
+    perm = torch.tensor([3, 0, 6, 1, 5, 2, 4])
+    a = savi(mode="decomp", x=videos, num_imgs=3, decode=False, init_noise=noise)["slot_history"]
+    b = savi(mode="decomp", x=videos, num_imgs=3, decode=False,
+             init_noise=noise[:, perm])["slot_history"]
+    assert max_abs(a[:, :, perm].cpu(), b.cpu()) < 5e-5

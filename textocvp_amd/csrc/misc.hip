@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void dec_tapsum_kernel(const float* __restrict
     out[i] = s;
 }
 
+// LearnedRandom slot initialiser: out[r, d] = mu[d] + sigma[d] * noise[r, d]
+__global__ __launch_bounds__(256) void slot_init_kernel(const float* __restrict__ mu,
+                                                        const float* __restrict__ sigma,
+                                                        const float* __restrict__ noise,
+                                                        float* __restrict__ out, long n, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % D);
+    out[i] = mu[d] + sigma[d] * noise[i];
+}
+
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
@@ -258,5 +269,14 @@ extern "C" int tocvp_dec_tapsum_f32(const float* w, float* out, int Cout, int Ci
     TOCVP_CHECK_ARG(w && out && Cout > 0 && Cin > 0);
     hipLaunchKernelGGL(dec_tapsum_kernel, dim3(blocks_for((long)25 * Cout * Cin, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, out, Cout, Cin);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_slot_init_f32(const float* mu, const float* sigma, const float* noise,
+                                   float* out, int rows, int D, void* stream) {
+    TOCVP_CHECK_ARG(mu && sigma && noise && out && rows >= 0 && D > 0);
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(slot_init_kernel, dim3(blocks_for((long)rows * D, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mu, sigma, noise, out, (long)rows * D, D);
     return tocvp_launch_status();
 }

@@ -1,0 +1,75 @@
+"""
+Rollout evaluation harness: this repo's counterpart of the reference's ``Evaluator.forward_eval``
+(05_evaluate_predictor.py:53-104) and of the nn.DataParallel wrapping in base/baseEvaluator.py
+(:142-145, :168-171), re-designed for one process per GPU.
+
+  * ``forward_eval``  -- the three module calls + reshape + clamp, identical glue to the reference.
+  * ``shard_batches`` -- whole reference batches are dealt round-robin to ranks (batch j -> rank
+    j mod W): caption padding is per batch and leaks into predictions, so only
+    batch-preserving sharding reproduces single-process results.
+  * ``gather_metrics`` -- ONE all-gather of the per-sequence (N_r, P) metric tensors at the end
+    (RCCL over xGMI on GPUs, gloo in the CPU tests); no communication inside the rollout.
+"""
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["forward_eval", "psnr_per_frame", "shard_batches", "gather_metrics"]
+
+
+@torch.no_grad()
+def forward_eval(decomp_model, predictor, videos, num_context, num_preds, **others):
+    """
+    videos (B, L, C, H, W) in [0,1]; ``others`` carries caption_tokens / caption_lengths
+    (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets).
+    """
+    B, L, C, H, W = videos.shape
+    if L < num_context + num_preds:
+        raise ValueError(f"Seq. length {L} smaller that {num_context = } + {num_preds = }")
+    num_slots, slot_dim = decomp_model.num_slots, decomp_model.slot_dim
+    out_model = decomp_model(mode="decomp", x=videos, num_imgs=num_context + num_preds,
+                             decode=False, **others)
+    slot_history = out_model["slot_history"]
+    pred_slots = predictor(slot_history, **others)
+    out_dec = decomp_model(mode="decode",
+                           slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
+    pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
+    targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)
+    return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,
+            "targets": targets, "masks": out_dec["masks"]}
+
+
+def psnr_per_frame(preds, targets, eps=1e-8):
+    """
+    (B, P, C, H, W) x2 -> (B, P) PSNR with piqa 1.2.2's definition 10*log10(1 / (mse + eps))
+    (lib/metrics.py:181-212).  Metric step AFTER the hot path: plain tensor
+    arithmetic, kept only so the multi-GPU gather has a real payload.
+    """
+    mse = ((preds - targets) ** 2).flatten(2).mean(dim=-1)
+    return 10.0 * torch.log10(1.0 / (mse + eps))
+
+
+def shard_batches(num_batches, rank, world_size):
+    """ indices of the reference batches owned by ``rank`` (round-robin, batch-preserving) """
+    return list(range(rank, num_batches, world_size))
+
+
+def gather_metrics(local, group=None):
+    """
+    local: (N_r, P) float tensor of per-sequence metrics on this rank (N_r may differ per rank).
+    Returns the (sum_r N_r, P) tensor in rank order on every rank, using a single padded
+    all-gather (+ one tiny all-gather of the row counts).
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    padded = torch.zeros((n_max,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    padded[:local.shape[0]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

@@ -63,6 +63,9 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
         ctypes.c_void_p]),
+    "tocvp_slot_init_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -282,14 +285,22 @@ def dec_tapsum(w):
     return out
 
 
-def dec_tail(x, w, bias, F, K):
-    """ x: (F*K, H, W, Cin) NHWC -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W) """
+def dec_tail(x, w, bias, F, K, out=None):
+    """
+    x: (F*K, H, W, Cin) NHWC -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W).
+    ``out`` = optional (imgs, recons, masks) contiguous views to write into.
+    """
     n, H, W, Cin = x.shape
     assert n == F * K and x.is_contiguous()
     dev = x.device
-    imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
-    recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
-    masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
+    if out is not None:
+        imgs, recons, masks = out
+        assert imgs.is_contiguous() and recons.is_contiguous() and masks.is_contiguous()
+        assert imgs.shape == (F, 3, H, W) and recons.shape == (F, K, 3, H, W)
+    else:
+        imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
+        recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
+        masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
     _check(lib().tocvp_dec_tail_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs),
                                     _ptr(recons), _ptr(masks), F, K, H, W, Cin, _stream()),
            "tocvp_dec_tail_f32")
@@ -304,4 +315,15 @@ def text_embed(tokens, tok_emb, pos_emb, gamma, beta, eps):
     _check(lib().tocvp_text_embed_f32(_ptr(tokens), _ptr(tok_emb), _ptr(pos_emb), _ptr(gamma),
                                       _ptr(beta), _ptr(out), B, L, D, tok_emb.shape[0], float(eps),
                                       _stream()), "tocvp_text_embed_f32")
+    return out
+
+
+def slot_init(mu, sigma, noise):
+    """ mu, sigma: (..., D) with D elements; noise: (B, K, D) on device -> mu + sigma * noise """
+    D = noise.shape[-1]
+    _dev_f32(noise, "noise")
+    noise = noise.contiguous()
+    out = torch.empty_like(noise)
+    _check(lib().tocvp_slot_init_f32(_ptr(mu), _ptr(sigma), _ptr(noise), _ptr(out),
+                                     noise.numel() // D, D, _stream()), "tocvp_slot_init_f32")
     return out

@@ -1,0 +1,271 @@
+"""
+Attention modules of the slot-rollout path on the MI355X kernels.
+
+Mirror of the reference's models/Blocks/attention.py (class names, constructor arguments,
+parameter names -> identical state_dict keys).  Forward passes call libtocvp kernels only:
+fp32-MFMA GEMMs with fused bias / ReLU / residual epilogues, one-wave-per-row LayerNorm,
+flash-style fp32-MFMA attention and the location-streaming slot-attention iteration.
+"""
+
+import torch
+import torch.nn as nn
+
+from ... import kernels as K
+from .model_utils import Derived, init_xavier_, require_inference
+
+__all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
+           "TransformerBlock", "TransformerDecoderBlock", "AdaptedEncoderBlock"]
+
+
+def _ln(x, ln, add=None):
+    return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add)
+
+
+def _mlp(x, seq, residual):
+    """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
+    h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU)
+    return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
+
+
+class SlotAttention(nn.Module):
+    """
+    Iterative slot attention (reference attention.py:12-128; algorithm :86-110).
+
+    Quirks kept for parity: ``scale = dim_feats ** -0.5`` (:46), softmax ACROSS SLOTS (:100),
+    LayerNorm eps 1e-3 (:49-51), 3 iterations on the first frame / 1 afterwards (:90).
+
+    ``forward`` keeps the reference signature.  SAVi uses the two halves separately so that the
+    k/v projection of all frames is batched: ``project_kv`` (LayerNorm + ONE fused [to_k; to_v]
+    GEMM) and ``iterate`` (the recurrent part).
+    ``store_attention_masks`` (default False) makes the kernel also write the (B, K, N)
+    attention tensor the reference keeps in ``self.attention_masks`` (:101).
+    """
+
+    def __init__(self, dim_feats, dim_slots, num_slots, num_iters_first=2, num_iters=2,
+                 mlp_hidden=128, epsilon=1e-8):
+        super().__init__()
+        self.dim_slots = dim_slots
+        self.num_iters_first = num_iters_first
+        self.num_iters = num_iters
+        self.num_slots = num_slots
+        self.epsilon = epsilon
+        self.scale = dim_feats ** -0.5
+
+        self.norm_input = nn.LayerNorm(dim_feats, eps=0.001)
+        self.norm_slot = nn.LayerNorm(dim_slots, eps=0.001)
+        self.norm_mlp = nn.LayerNorm(dim_slots, eps=0.001)
+        self.to_q = nn.Linear(dim_slots, dim_slots)
+        self.to_k = nn.Linear(dim_feats, dim_slots)
+        self.to_v = nn.Linear(dim_feats, dim_slots)
+        self.gru = nn.GRUCell(dim_slots, dim_slots)
+        self.mlp = nn.Sequential(
+            nn.Linear(dim_slots, mlp_hidden), nn.ReLU(), nn.Linear(mlp_hidden, dim_slots))
+
+        self.store_attention_masks = False
+        self.attention_masks = None
+        self._derived = Derived()
+        self._ws = None
+
+    # -- k/v projection (once per frame; batched over frames by SAVi) --------------------------
+    def project_kv(self, inputs):
+        """ inputs (..., N, Df) -> fused kv (..., N, 2*D): k = [..., :D], v = [..., D:] """
+        w = self._derived.get("w_kv", [self.to_k.weight, self.to_v.weight],
+                              lambda: torch.cat([self.to_k.weight, self.to_v.weight], 0).contiguous())
+        b = self._derived.get("b_kv", [self.to_k.bias, self.to_v.bias],
+                              lambda: torch.cat([self.to_k.bias, self.to_v.bias], 0).contiguous())
+        return K.linear(_ln(inputs, self.norm_input), w, b)
+
+    # -- recurrent refinement ------------------------------------------------------------------
+    def iterate(self, kv, slots, num_iters):
+        """ kv (B, N, 2D) from project_kv, slots (B, K, D) -> refined slots (B, K, D) """
+        B, Ks, D = slots.shape
+        k, v = kv[..., :D], kv[..., D:]
+        N = kv.shape[1]
+        need = K.lib().tocvp_slot_attn_ws_bytes(B, N)
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != slots.device:
+            self._ws = torch.empty((need + 3) // 4, device=slots.device, dtype=torch.float32)
+        attn = None
+        for _ in range(num_iters):
+            prev = slots
+            q = K.linear(_ln(slots, self.norm_slot), self.to_q.weight, self.to_q.bias)
+            if self.store_attention_masks:
+                attn = torch.empty((B, Ks, N), device=slots.device, dtype=torch.float32)
+            upd = K.slot_attn_iter(q, k, v, self.scale, self.epsilon, attn_out=attn, ws=self._ws)
+            gi = K.linear(upd, self.gru.weight_ih, self.gru.bias_ih)
+            gh = K.linear(prev, self.gru.weight_hh, self.gru.bias_hh)
+            slots = K.gru_gates(gi, gh, prev)
+            slots = _mlp(_ln(slots, self.norm_mlp), self.mlp, residual=slots)
+        self.attention_masks = attn
+        return slots
+
+    def forward(self, inputs, slots, step=0, **kwargs):
+        """ inputs (B, N, Df), slots (B, K, D) -> slots (B, K, D)   (reference :67-112) """
+        require_inference(self)
+        self.attention_masks = None
+        n_it = self.num_iters_first if step == 0 else self.num_iters
+        return self.iterate(self.project_kv(inputs.contiguous()), slots.contiguous(), n_it)
+
+    def get_attention_masks(self, shape=None):
+        """ last attention (B, K, N[ -> *shape]) -- needs ``store_attention_masks = True`` """
+        if self.attention_masks is None:
+            raise RuntimeError("set slot_attention.store_attention_masks = True before the forward")
+        m = self.attention_masks
+        return m if shape is None else m.reshape(m.shape[0], m.shape[1], *shape)
+
+
+class MetaAttention(nn.Module):
+    """ q/k/v/out parameter holder shared by self- and cross-attention (reference :136-215). """
+
+    def __init__(self, emb_dim, num_heads=1, dropout=0., out_dim=None, **kwargs):
+        assert num_heads >= 1
+        if emb_dim % num_heads != 0:
+            raise ValueError(f"{emb_dim = } must be divisible by {num_heads}...")
+        if dropout != 0.:
+            raise NotImplementedError("attention dropout is a training feature (inference-only path)")
+        super().__init__()
+        out_dim = out_dim if out_dim is not None else emb_dim
+        self.emb_dim = emb_dim
+        self.num_heads = num_heads
+        self.q = nn.Linear(emb_dim, emb_dim, bias=False)
+        self.k = nn.Linear(emb_dim, emb_dim, bias=False)
+        self.v = nn.Linear(emb_dim, emb_dim, bias=False)
+        self.drop = nn.Dropout(dropout)
+        self.out_projection = nn.Sequential(nn.Linear(emb_dim, out_dim, bias=False))
+        self.attention_masks = None
+        self._derived = Derived()
+
+    def forward(self, x):
+        raise NotImplementedError("Base-Class does not implement a 'forward' method...")
+
+
+class MultiHeadSelfAttention(MetaAttention):
+    """
+    Bias-free multi-head self-attention (reference :219-265).  q, k and v come from ONE GEMM
+    against the concatenated (3E, E) weight; the attention kernel reads the three column
+    slices of that buffer in place.  ``residual`` is fused into the output-projection epilogue.
+    """
+
+    def __init__(self, emb_dim, num_heads=8, dropout=0.):
+        super().__init__(emb_dim=emb_dim, num_heads=num_heads, dropout=dropout)
+
+    def forward(self, x, residual=None, **kwargs):
+        if kwargs.get("mask", None) is not None:
+            raise NotImplementedError("attention masks are not used on the slot-rollout path")
+        E = x.shape[-1]
+        w = self._derived.get(
+            "w_qkv", [self.q.weight, self.k.weight, self.v.weight],
+            lambda: torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous())
+        qkv = K.linear(x, w)                                              # (B, T, 3E)
+        o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], self.num_heads,
+                  (E // self.num_heads) ** -0.5)
+        return K.linear(o, self.out_projection[0].weight, residual=residual)
+
+
+class MultiHeadCrossAttention(MetaAttention):
+    """
+    Text-to-slot cross-attention (reference :269-319).  Keys/values depend only on the text and
+    are therefore projected once per sequence (``project_kv``) and reused by all rollout steps.
+    No key-padding mask: padded text positions participate, as in the reference (:314).
+    """
+
+    def __init__(self, emb_dim, dim_head, kv_dim, num_heads=8, dropout=0.):
+        super().__init__(emb_dim=emb_dim, num_heads=num_heads, dropout=dropout)
+        self.dim_head = dim_head
+        inner_dim = dim_head * num_heads
+        self.q = nn.Linear(emb_dim, inner_dim, bias=False)
+        self.k = nn.Linear(kv_dim, inner_dim, bias=False)
+        self.v = nn.Linear(kv_dim, inner_dim, bias=False)
+        self.out_projection = nn.Linear(inner_dim, emb_dim)
+
+    def project_kv(self, enc_embs):
+        """ normalised text (B, Lt, kv_dim) -> fused (B, Lt, 2*inner) [k | v] """
+        w = self._derived.get("w_kv", [self.k.weight, self.v.weight],
+                              lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
+        return K.linear(enc_embs, w)
+
+    def forward(self, enc_embs, query_embs, residual=None, kv=None, **kwargs):
+        if kv is None:
+            kv = self.project_kv(enc_embs)
+        inner = self.q.weight.shape[0]
+        q = K.linear(query_embs, self.q.weight)
+        o = K.mha(q, kv[..., :inner], kv[..., inner:], self.num_heads, self.dim_head ** -0.5)
+        return K.linear(o, self.out_projection.weight, self.out_projection.bias, residual=residual)
+
+
+class TransformerBlock(nn.Module):
+    """
+    Transformer encoder block (reference :323-396): pre-norm by default, POST-norm when used as the
+    SAVi transition (transition_models.py:24-29).  LayerNorm eps 1e-6.
+    """
+
+    def __init__(self, embed_dim, num_heads, mlp_size, pre_norm=True):
+        super().__init__()
+        assert num_heads >= 1
+        self.embed_dim, self.mlp_size, self.num_heads, self.pre_norm = \
+            embed_dim, mlp_size, num_heads, pre_norm
+        self.attn = MultiHeadSelfAttention(emb_dim=embed_dim, num_heads=num_heads)
+        self.mlp = nn.Sequential(
+            nn.Linear(embed_dim, mlp_size), nn.ReLU(), nn.Linear(mlp_size, embed_dim))
+        self.layernorm_query = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.layernorm_mlp = nn.LayerNorm(embed_dim, eps=1e-6)
+        init_xavier_(self)
+
+    def forward(self, inputs):
+        assert inputs.ndim == 3
+        require_inference(self)
+        inputs = inputs.contiguous()
+        if self.pre_norm:
+            y = self.attn(_ln(inputs, self.layernorm_query), residual=inputs)
+            return _mlp(_ln(y, self.layernorm_mlp), self.mlp, residual=y)
+        y = _ln(self.attn(inputs, residual=inputs), self.layernorm_query)
+        return _ln(_mlp(y, self.mlp, residual=y), self.layernorm_mlp)
+
+
+class TransformerDecoderBlock(nn.Module):
+    """ Cross-attention + MLP, both pre-norm with residuals (reference :400-467). """
+
+    def __init__(self, embed_dim, head_dim, kv_dim, num_heads, mlp_size):
+        super().__init__()
+        self.ln_mlp = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.mlp = nn.Sequential(
+            nn.Linear(embed_dim, mlp_size), nn.ReLU(), nn.Linear(mlp_size, embed_dim))
+        self.ln_cross_att_q = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.ln_cross_att_kv = nn.LayerNorm(kv_dim, eps=1e-6)
+        self.cross_attn = MultiHeadCrossAttention(
+            emb_dim=embed_dim, dim_head=head_dim, num_heads=num_heads, kv_dim=kv_dim)
+
+    def project_text(self, feats):
+        """ step-invariant half of the block: LayerNorm(text) -> fused K/V projection """
+        return self.cross_attn.project_kv(_ln(feats.contiguous(), self.ln_cross_att_kv))
+
+    def forward(self, queries, feats, text_kv=None):
+        assert queries.ndim == 3
+        if text_kv is None:
+            text_kv = self.project_text(feats)
+        z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q), residual=queries,
+                            kv=text_kv)
+        return _mlp(_ln(z, self.ln_mlp), self.mlp, residual=z)
+
+
+class AdaptedEncoderBlock(TransformerBlock):
+    """
+    Predictor layer: self-attention, text cross-attention block, MLP (reference :471-534).
+    The last residual is taken from ``y`` (output of the self-attention stage), NOT from the
+    cross-attention branch -- reference wiring at :521-523, reproduced on purpose.
+    """
+
+    def __init__(self, embed_dim, num_heads, mlp_size, fusion_params):
+        super().__init__(embed_dim=embed_dim, num_heads=num_heads, mlp_size=mlp_size)
+        self.cross_attention = TransformerDecoderBlock(
+            embed_dim=embed_dim, kv_dim=embed_dim, head_dim=fusion_params.get("head_dim"),
+            num_heads=fusion_params.get("num_heads"), mlp_size=fusion_params.get("mlp_size"))
+
+    def forward(self, x, text_embeddings, text_kv=None):
+        assert x.ndim == 3, f"Input 'x' must have 3 dims, but got {x.shape = }..."
+        y = self.attn(_ln(x, self.layernorm_query), residual=x)
+        z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
+        return _mlp(_ln(z, self.layernorm_mlp), self.mlp, residual=y)
+
+    def condition_slots_given_caption(self, slots_to_condition, text_embeddings, text_kv=None):
+        return self.cross_attention(queries=slots_to_condition, feats=text_embeddings,
+                                    text_kv=text_kv)

@@ -1,0 +1,49 @@
+"""
+Parameter-initialisation helper and the derived-weight cache used by the module mirrors.
+Reference counterpart: models/Blocks/model_utils.py:66-79 (init_xavier_).
+"""
+
+import torch
+import torch.nn as nn
+
+__all__ = ["init_xavier_", "Derived", "require_inference"]
+
+
+@torch.no_grad()
+def init_xavier_(model: nn.Module):
+    """ xavier-uniform for >=2-d parameters, zeros for '*.bias' (model_utils.py:66-79). """
+    for name, p in model.named_parameters():
+        if name.endswith(".bias"):
+            p.zero_()
+        elif p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class Derived:
+    """
+    Cache of tensors derived from parameters (fused / repacked weights, position tables, the
+    collapsed decoder layer 0).  An entry is rebuilt whenever one of its source parameters was
+    replaced, moved or modified in place (data_ptr / _version / device signature), so
+    ``load_state_dict`` and ``.to(device)`` invalidate it without any hook.
+    """
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, sources, builder):
+        sig = tuple((t.data_ptr(), t._version, t.device.index) for t in sources)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = builder()
+        self._store[key] = (sig, val)
+        return val
+
+
+def require_inference(module):
+    """ The HIP path has no backward kernels yet (training is a later SURVEY 8f row). """
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise RuntimeError(
+            f"{type(module).__name__}: the MI355X kernels are inference-only; call under "
+            f"torch.no_grad() (as the reference evaluator does, base/baseEvaluator.py:175)")

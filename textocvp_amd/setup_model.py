@@ -1,0 +1,99 @@
+"""
+Factories and checkpoint loading with the reference's contract (lib/setup_model.py:21-53
+setup_model, :57-132 setup_predictor, :189-240 load_checkpoint), minus the optimiser/scheduler
+parts (training is a later SURVEY 8f row).
+"""
+
+import copy
+import os
+
+import torch
+
+from .models.SAVi import SAVi
+from .models.Predictors.predictor_wrapper import PredictorWrapper
+from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
+
+__all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params"]
+
+# configs/models/SAVi.json + configs/predictors/TextOCVP_CustomTF.json + CONFIG.py:66-71 defaults
+_SAVI_DEFAULT = {
+    "num_slots": 8, "slot_dim": 128, "num_iterations_first": 3, "num_iterations": 1,
+    "in_channels": 3, "mlp_hidden": 256, "mlp_encoder_dim": 128, "initializer": "LearnedRandom",
+    "transition_module": {"model_name": "TransformerBlock", "num_heads": 4, "mlp_size": 512},
+    "encoder": {"encoder_name": "ConvEncoder", "encoder_params": {
+        "num_channels": [32, 32, 32, 32], "kernel_size": 5, "resolution": [64, 64],
+        "downsample_encoder": False, "downsample": 2}},
+    "decoder": {"decoder_name": "ConvDecoder", "decoder_params": {
+        "num_channels": [64, 64, 64, 64], "kernel_size": 5, "resolution": [64, 64],
+        "downsample_decoder": False, "upsample": 1}},
+}
+_PREDICTOR_DEFAULT = {
+    "predictor_name": "TextOCVP_CustomTF",
+    "predictor_params": {
+        "predictor_params": {"token_dim": 512, "n_heads": 8, "hidden_dim": 2048, "num_layers": 8,
+                             "residual": True},
+        "fusion_params": {"num_heads": 8, "head_dim": 64, "mlp_size": 2048},
+        "text_encoder_params": {"input_dim": 128, "num_layers": 2, "num_heads": 4, "vocab_size": 50},
+    },
+}
+
+
+def default_exp_params(num_slots=8, num_context=1, num_preds=9, input_buffer_size=10,
+                       teacher_force=False):
+    """ experiment_params.json-shaped dict with the shipped SAVi / TextOCVP_CustomTF configs """
+    model = copy.deepcopy(_SAVI_DEFAULT)
+    model["num_slots"] = num_slots
+    return {
+        "model": {"model_name": "SAVi", "model_params": model},
+        "predictor": copy.deepcopy(_PREDICTOR_DEFAULT),
+        "prediction_params": {"num_context": num_context, "num_preds": num_preds,
+                              "teacher_force": teacher_force,
+                              "input_buffer_size": input_buffer_size},
+    }
+
+
+def setup_model(model_params):
+    """ ``exp_params["model"]`` -> decomposition model (lib/setup_model.py:21-53) """
+    name = model_params["model_name"]
+    # the reference's encoder/decoder factories pop keys from the dict; keep the caller's intact
+    params = copy.deepcopy(model_params["model_params"])
+    if name == "SAVi":
+        return SAVi(**params)
+    raise NotImplementedError(f"'{name = }' is not built yet (supported: ['SAVi'])")
+
+
+def setup_predictor(exp_params):
+    """ experiment params -> PredictorWrapper around the predictor (lib/setup_model.py:57-132) """
+    model_params = exp_params["model"]["model_params"]
+    name = exp_params["predictor"]["predictor_name"]
+    pp = exp_params["predictor"]["predictor_params"]
+    if name == "TextOCVP_CustomTF":
+        inner = copy.deepcopy(pp["predictor_params"])
+        inner["input_buffer_size"] = exp_params["prediction_params"]["input_buffer_size"]
+        core = TextOCVP_CustomTF(slot_dim=model_params["slot_dim"], predictor_params=inner,
+                                 fusion_params=pp.get("fusion_params"),
+                                 text_encoder_params=pp.get("text_encoder_params"))
+    else:
+        raise NotImplementedError(f"predictor {name!r} is not built yet (SURVEY 8f rank 4)")
+    return PredictorWrapper(exp_params=exp_params, predictor=core)
+
+
+def load_checkpoint(checkpoint_path, model, only_model=True, map_cpu=False, **kwargs):
+    """
+    Strict load of ``torch.load(path)['model_state_dict']`` (lib/setup_model.py:189-227),
+    including the 'predictor.' prefix shim for bare-predictor checkpoints (:214-221).
+    """
+    if checkpoint_path is None:
+        return model
+    if not os.path.exists(checkpoint_path):
+        raise FileNotFoundError(f"Checkpoint {checkpoint_path} does not exist ...")
+    ckpt = torch.load(checkpoint_path, map_location="cpu" if map_cpu else None)
+    sd = ckpt["model_state_dict"]
+    first_model = next(iter(model.state_dict().keys()))
+    first_ckpt = next(iter(sd.keys()))
+    if first_model.startswith("predictor") and not first_ckpt.startswith("predictor"):
+        sd = {f"predictor.{k}": v for k, v in sd.items()}
+    model.load_state_dict(sd)
+    if not only_model:
+        raise NotImplementedError("optimizer / scheduler state is a training feature (not built)")
+    return model
