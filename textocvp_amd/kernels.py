@@ -75,6 +75,37 @@ class TocvpError(RuntimeError):
     pass
 
 
+class LaunchTimer:
+    """
+    Optional per-launch device timing of selected kernels with HIP events recorded on the stream
+    the kernel is enqueued on (torch's current stream).  bench.py uses it to measure the average
+    launch duration of the dominant kernel inside the timed region; it is off by default.
+    """
+
+    def __init__(self):
+        self.records = {}          # name -> list of (start_event, stop_event, work_units)
+
+    def wrap(self, name, units, fn):
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = fn()
+        stop.record()
+        self.records.setdefault(name, []).append((start, stop, units))
+        return out
+
+    def summary(self):
+        """ name -> dict(launches, total_ms, units) ; call after torch.cuda.synchronize() """
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = {"launches": len(recs), "total_ms": ms, "units": sum(u for _, _, u in recs)}
+        return out
+
+
+TIMER = None   # set to a LaunchTimer() to time conv launches
+
+
 def lib():
     """ Load libtocvp.so once; raise loudly when it is missing (no CPU / torch fallback). """
     global _LIB
@@ -255,8 +286,13 @@ def conv5x5(x, wp, bias, relu=True, out=None):
     assert x.is_contiguous() and wp.shape[0] == 25 and wp.shape[2] == Cin
     if out is None:
         out = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
-    _check(lib().tocvp_conv5x5_f32(_ptr(x), None, 0, _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
-                                   Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
+    def run():
+        _check(lib().tocvp_conv5x5_f32(_ptr(x), None, 0, _ptr(wp), _ptr(bias), _ptr(out), n, H, W,
+                                       Cin, Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
+    if TIMER is not None:
+        TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
+    else:
+        run()
     return out
 
 
@@ -271,8 +307,14 @@ def conv5x5_collapsed(cpos, S, wp, bias, relu=True, out=None):
     assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
     if out is None:
         out = torch.empty((n, H, W, Cout), device=cpos.device, dtype=torch.float32)
-    _check(lib().tocvp_conv5x5_f32(_ptr(cpos), _ptr(S), 1, _ptr(wp), _ptr(bias), _ptr(out), n, H, W,
-                                   Cin, Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
+    def run():
+        _check(lib().tocvp_conv5x5_f32(_ptr(cpos), _ptr(S), 1, _ptr(wp), _ptr(bias), _ptr(out), n, H,
+                                       W, Cin, Cout, int(bool(relu)), _stream()),
+               "tocvp_conv5x5_f32")
+    if TIMER is not None:
+        TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
+    else:
+        run()
     return out
 
 
