@@ -1,0 +1,71 @@
+"""
+N > 1 path on CPU: two gloo ranks shard whole reference batches round-robin and all-gather their
+ragged per-sequence metric tensors once; the result must equal the single-process order-by-rank
+concatenation.  (On the GPU node the same code runs over RCCL; no collective exists inside the
+rollout itself.)
+"""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from textocvp_amd.evaluator import gather_metrics, psnr_per_frame, shard_batches
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _metrics_for_batch(j, P=5):
+    """ deterministic stand-in for the (B_j, P) PSNR rows of reference batch j (ragged B_j) """
+    g = torch.Generator().manual_seed(1000 + j)
+    bj = 2 + (j % 3)
+    preds = torch.rand(bj, P, 3, 8, 8, generator=g)
+    targets = torch.rand(bj, P, 3, 8, 8, generator=g)
+    return psnr_per_frame(preds, targets)
+
+
+def _worker(rank, world, port, num_batches, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_batches(num_batches, rank, world)
+    local = torch.cat([_metrics_for_batch(j) for j in mine], dim=0) if mine else torch.zeros(0, 5)
+    full = gather_metrics(local)
+    torch.save({"full": full, "mine": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process(tmp_path):
+    world, num_batches = 2, 7
+    mp.spawn(_worker, args=(world, _free_port(), num_batches, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    # batch-preserving round-robin: every batch owned exactly once
+    owned = sorted(j for o in outs for j in o["mine"])
+    assert owned == list(range(num_batches))
+    assert outs[0]["mine"] == [0, 2, 4, 6] and outs[1]["mine"] == [1, 3, 5]
+    expect = torch.cat([_metrics_for_batch(j) for r in range(world)
+                        for j in shard_batches(num_batches, r, world)], dim=0)
+    for o in outs:
+        assert torch.equal(o["full"], expect)
+    # the aggregate is independent of the sharding
+    single = torch.cat([_metrics_for_batch(j) for j in range(num_batches)], dim=0)
+    assert torch.allclose(expect.mean(), single.mean(), atol=1e-6)
+    assert torch.allclose(expect.sum(0).sort().values, single.sum(0).sort().values, atol=1e-4)
+
+
+def test_single_process_gather_is_identity():
+    x = torch.arange(12.0).reshape(4, 3)
+    assert torch.equal(gather_metrics(x), x)
+
+
+def test_psnr_definition():
+    a = torch.zeros(1, 1, 3, 4, 4)
+    b = torch.full((1, 1, 3, 4, 4), 0.1)
+    assert abs(psnr_per_frame(a, b).item() - 10 * torch.log10(torch.tensor(1 / (0.01 + 1e-8))).item()) < 1e-4
