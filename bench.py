@@ -30,8 +30,16 @@ sys.path.insert(0, ROOT)
 
 NUM_SLOTS, NUM_CONTEXT, NUM_PREDS, RES = 30, 1, 19, 64
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA (same table)
 CONV_GFLOP_PER_SLOT_IMAGE = 2 * RES * RES * 64 * 64 * 25 / 1e9   # 0.839: one 64->64 5x5 layer
 PATH_GFLOP_PER_FRAME = 149.5             # reference algorithm, K=30
+
+
+ARITH = {
+    ("fp32", "fp32"): "fp32",
+    ("bf16x3", "bf16x6"): "bf16 split operands (decoder convs bf16x3, predictor GEMMs bf16x6), fp32 "
+                          "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
+}
 
 
 def parse():
@@ -173,9 +181,18 @@ def main():
                 if rec.get("slot_images_per_launch"):
                     traffic = rec["hbm_bytes_per_launch"] * (
                         conv["units"] / conv["launches"]) / rec["slot_images_per_launch"]
-            roofline = {"bound": "mfma", "kernel": "conv5x5_mfma_kernel<64,64> (decoder 5x5 conv)",
-                        "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            split = savi.decoder.conv_precision == "bf16x3"
+            # split-bf16 executes 3 bf16 MFMA products per algorithmic product; `achieved` stays
+            # ALGORITHMIC flops / time, `peak` is the dense MFMA peak of the operand dtype
+            peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            roofline = {"bound": "mfma",
+                        "kernel": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 "
+                                   "operands, 3 MFMA products per algorithmic product)") if split
+                        else "conv5x5_mfma_kernel<64,64> (decoder 5x5 conv, exact fp32 MFMA)",
+                        "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "mfma_products_per_flop": 3 if split else 1,
+                        "frac_executed_mfma": round((3 if split else 1) * achieved / peak, 4),
                         "traffic": traffic, "launches": conv["launches"],
                         "avg_launch_ms": round(avg_ms, 4),
                         "gflop_per_launch": round(gflop_per_launch, 2),
@@ -186,7 +203,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": ARITH.get((savi.decoder.conv_precision, pred.predictor.gemm_precision),
+                               f"decoder {savi.decoder.conv_precision} / predictor "
+                               f"{pred.predictor.gemm_precision}"),
+            "data": "synthetic",
             "config": {"workload": "configs[1]: SAVi 30-slot 64x64 + TextOCVP_CustomTF predictor, "
                                    "1 seed + 19 preds (encode 20 frames, 19 rollout steps, "
                                    "decode 19 frames)",

@@ -65,6 +65,20 @@ int tocvp_gemm_f32(const float* A, int lda, const float* W, const float* bias,
                    float* C, int ldc, int M, int N, int K, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Same contract as tocvp_gemm_f32 (fp32 A, C, bias, R, rowvec in HBM) with SPLIT-bf16 operands on
+ * the bf16 matrix cores:
+ *   nsplit = 2 ("bf16x3"): x = hi + lo,       hh + hl + lh            (~2^-16 per product)
+ *   nsplit = 3 ("bf16x6"): x = hi + mid + lo, hh + hm + mh + hl + mm + lh   (fp32-class accuracy)
+ * A is split while staged into LDS; Wsplit = (N, nsplit, K) bf16 planes from
+ * tocvp_split_weights_bf16 (done once per weight).  Requires K % 32 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_split_weights_bf16(const float* w, void* out, int N, int K, int nsplit, void* stream);
+int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsplit, int nsplit,
+                             const float* bias, const float* R, int ldr,
+                             const float* rowvec, int rv_div, int rv_mod, int rv_flip,
+                             float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y[r,:] = LayerNorm(x[r,:] + add[r % add_rows,:]) * gamma + beta      (biased variance, eps)
  * Replaces nn.LayerNorm at attention.py:49-51,361-362,427,435-436, SAVi.py:116 and
  * text_encoders.py:63,65-68; `add` (may be NULL) fuses SoftPositionEmbed's addend
@@ -146,6 +160,19 @@ int tocvp_pack_conv_weights_f32(const float* w, float* wp, int Cout, int Cin, in
 int tocvp_conv5x5_f32(const float* x, const float* aux, int in_mode, const float* wp,
                       const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
                       int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Same convolution (Cin == Cout == 64 only, fp32 tensors in HBM on both sides) evaluated with
+ * SPLIT-bf16 operands on the bf16 matrix cores: x = hi + lo (two bf16), products as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation ("bf16x3", per-product relative error ~2^-16).
+ * 5.3x fewer matrix-pipe cycles per FLOP than the fp32 MFMA path of tocvp_conv5x5_f32.
+ *   wsplit: weights pre-split by tocvp_split_conv_weights_bf16 as (25, Cout, [hi Cin | lo Cin]) bf16.
+ *   in_mode / aux as in tocvp_conv5x5_f32.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout, int Cin, void* stream);
+int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode, const void* wsplit,
+                             const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
+                             int relu, void* stream);
 
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of

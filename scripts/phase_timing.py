@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from textocvp_amd import synth, kernels
 from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
 B = int(sys.argv[1])

@@ -231,3 +231,42 @@ def test_text_embed():
     ref = O.layer_norm(te[tokens] + pe[:20][None], g, b, 1e-8) * (tokens != 0).unsqueeze(-1)
     got = k.text_embed(tokens.to(DEV), te.to(DEV), pe.to(DEV), g.to(DEV), b.to(DEV), 1e-8)
     close(got, ref)
+
+
+@pytest.mark.parametrize("n", [3, 37])
+def test_conv5x5_bf16x3_accuracy(n):
+    """ split-bf16 conv: error relative to the fp64 result must be ~1e-5 of the output scale """
+    k = _k()
+    x = rnd("bx", (n, 64, 64, 64))
+    w = rnd("bw", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("bb", (64,), "uniform", 0.1)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2))
+    ref = ref.permute(0, 2, 3, 1)
+    ws = k.split_conv_weights_bf16(w.to(DEV))
+    got = k.conv5x5_bf16x3(x.to(DEV), ws, b.to(DEV), relu=True)
+    err = (got.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"bf16x3 conv: max abs err {err:.3e} at scale {scale:.3g}")
+    assert err < 4e-5 * scale
+    # fp32 MFMA path on the same data for comparison
+    got32 = k.conv5x5(x.to(DEV), k.pack_conv_weights(w.to(DEV)), b.to(DEV), relu=True)
+    err32 = (got32.cpu().double() - ref).abs().max().item()
+    assert err32 < 5e-6 * scale
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("bf16x6", 2e-6)])
+@pytest.mark.parametrize("M,N,K", [(30, 512, 512), (9600, 2048, 512), (301, 512, 2048)])
+def test_gemm_split_bf16(mode, tol, M, N, K):
+    """ split-bf16 GEMMs against an fp64 reference; bf16x6 must be fp32-class """
+    k = _k()
+    x, w, b = rnd("sx", (M, K)), rnd("sw", (N, K), "uniform", K ** -0.5), rnd("sb", (N,))
+    res = rnd("sres", (M, N))
+    ref = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()
+    got = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU, residual=res.to(DEV),
+                   precision=mode)
+    err = (got.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    got32 = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU, residual=res.to(DEV))
+    err32 = (got32.cpu().double() - ref).abs().max().item()
+    print(f"{mode} gemm {M}x{N}x{K}: err {err:.2e} (fp32 mfma {err32:.2e}) at scale {scale:.3g}")
+    assert err < tol * scale

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs p) {
         for (int tap = 0; tap < 25; ++tap) {
             const int buf = tap & 1;
             if (tap + 1 < 25) wload(tap + 1, ch);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs
             const int dy = tap / 5, dx = tap % 5;
             const float* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * CS + 4 * h;
             const float* b_base = w_s + buf * COUT * CS + l31 * CS + 4 * h;

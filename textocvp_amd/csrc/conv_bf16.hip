@@ -1,0 +1,207 @@
+// 5x5 convolution (64 -> 64 channels) with SPLIT-bf16 operands on the bf16 matrix cores.
+//
+// Every fp32 operand x is split into hi = bf16(x) and lo = bf16(x - hi) (16 significant bits
+// together).  A product block is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation
+// ("bf16x3"): three v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16 each) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles, K = 2 each) -> 5.3x fewer matrix-pipe cycles per FLOP at a
+// per-product relative error of ~2^-16 (dropped lo*lo term and the 16-bit operand truncation).
+// fp32 in HBM on both sides: the split happens while the halo tile is staged into LDS (each
+// element is split once per tile and reused by 25 taps x 64 output channels), weights are
+// pre-split once.
+//
+// Geometry is that of conv5x5_mfma_kernel (conv.hip): 8 x 32 pixel tile x 64 output channels per
+// 4-wave workgroup, halo tile staged once, per-tap weight slices double buffered.  LDS image per
+// pixel / per output channel: [64 hi bf16 | 64 lo bf16 | 16 B pad] = 272 B, so the 16 rows of
+// every ds_read_b128 lane group land on 16 distinct 16-byte slots.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 32, IH = TH + 4, IW = TW + 4;
+constexpr int C = 64;
+constexpr int ROWB = 2 * C * 2 + 16;   // 272 bytes per pixel / per output channel
+
+struct ConvArgs {
+    const float* x; const float* aux; const unsigned char* wsplit; const float* bias; float* y;
+    int nimg, H, W, relu;
+};
+
+__device__ __forceinline__ int border_class(int p, int n) {
+    return p < 2 ? p : (p >= n - 2 ? 4 - (n - 1 - p) : 2);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        hi[u] = (__bf16)v[u];
+        lo[u] = (__bf16)(v[u] - (float)hi[u]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv5x5_bf16x3_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IH * IW * ROWB + 2 * C * ROWB];
+    unsigned char* in_s = lds;
+    unsigned char* w_s = lds + IH * IW * ROWB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_x = p.W / TW, tiles = tiles_x * (p.H / TH);
+    const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-tap weight slice: 64 output channels x 256 B (hi | lo) = 1024 16-byte chunks
+    f32x4 wreg[4];
+    auto wload = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wreg[i] = *reinterpret_cast<const f32x4*>(p.wsplit + ((size_t)tap * C * 256) +
+                                                      (size_t)(t + 256 * i) * 16);
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i;
+            *reinterpret_cast<f32x4*>(w_s + buf * C * ROWB + (idx >> 4) * ROWB + (idx & 15) * 16) =
+                wreg[i];
+        }
+    };
+
+    wload(0);
+    // ---- halo tile: fp32 -> (hi, lo) bf16 planes in LDS
+    for (int i = t; i < IH * IW * (C / 4); i += 256) {
+        const int pix = i / (C / 4), c = (i % (C / 4)) * 4;
+        const int iy = ty0 + pix / IW - 2, ix = tx0 + pix % IW - 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            if (MODE == 0) {
+                v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * p.H + iy) * p.W + ix) * C + c);
+            } else {
+                const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
+                v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)iy * p.W + ix) * C + c) +
+                    *reinterpret_cast<const f32x4*>(p.aux + ((size_t)img * 25 + cls) * C + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+            }
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + c * 2) = hi;
+        *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + C * 2 + c * 2) = lo;
+    }
+    wstore(0);
+    __syncthreads();
+
+    for (int tap = 0; tap < 25; ++tap) {
+        const int buf = tap & 1;
+        if (tap + 1 < 25) wload(tap + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it)
+        const int dy = tap / 5, dx = tap % 5;
+        const unsigned char* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * ROWB + h * 16;
+        const unsigned char* b_base = w_s + buf * C * ROWB + l31 * ROWB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32);
+                al[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32 + C * 2);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bh[n] = *reinterpret_cast<const bf16x8*>(b_base + n * 32 * ROWB + ks * 32);
+                bl[n] = *reinterpret_cast<const bf16x8*>(b_base + n * 32 * ROWB + ks * 32 + C * 2);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
+                    acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
+                    acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
+                }
+        }
+        if (tap + 1 < 25) wstore(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float bv = p.bias[n * 32 + l31];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = ty0 + 2 * wave + m;
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C + n * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                yrow[(size_t)acc_row(r, h) * C] = v;
+            }
+        }
+    }
+}
+
+// (Cout, Cin, 5, 5) fp32 -> [tap][cout][hi Cin | lo Cin] bf16
+__global__ __launch_bounds__(256) void split_conv_weights_kernel(const float* __restrict__ w,
+                                                                 __bf16* __restrict__ out, int Cout,
+                                                                 int Cin) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)25 * Cout * Cin) return;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tap = (int)(i / ((long)Cin * Cout));
+    const float v = w[((size_t)co * Cin + ci) * 25 + tap];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    __bf16* o = out + ((size_t)tap * Cout + co) * 2 * Cin;
+    o[ci] = hi;
+    o[Cin + ci] = lo;
+}
+
+}  // namespace
+
+extern "C" int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout, int Cin,
+                                             void* stream) {
+    TOCVP_CHECK_ARG(w && out && Cout > 0 && Cin > 0);
+    const long n = (long)25 * Cout * Cin;
+    hipLaunchKernelGGL(split_conv_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out), Cout, Cin);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode,
+                                        const void* wsplit, const float* bias, float* y, int nimg,
+                                        int H, int W, int Cin, int Cout, int relu, void* stream) {
+    TOCVP_CHECK_ARG(x && wsplit && bias && y);
+    TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
+    TOCVP_CHECK_ARG(Cin == C && Cout == C);
+    TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0 && (W % TW) == 0);
+    TOCVP_CHECK_ARG((size_t)nimg * (H / TH) * (W / TW) < 0x7fffffffu);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(wsplit) || (aux && !tocvp_aligned16(aux)))
+        return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    ConvArgs a{x, aux, static_cast<const unsigned char*>(wsplit), bias, y, nimg, H, W, relu};
+    const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_mode == 0)
+        hipLaunchKernelGGL(conv5x5_bf16x3_kernel<0>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv5x5_bf16x3_kernel<1>, grid, dim3(256), 0, s, a);
+    return tocvp_launch_status();
+}

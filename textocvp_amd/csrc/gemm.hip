@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload((kt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it)
         const float* a_base = As + buf * BM * LS + (wm * WM + l31) * LS + 4 * h;
         const float* b_base = Bs + buf * BN * LS + (wn * WN + l31) * LS + 4 * h;
 #pragma unroll

@@ -8,6 +8,7 @@ library is missing or a call fails, this module raises.
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -25,6 +26,14 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_split_weights_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_gemm_bf16split_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
     "tocvp_layernorm_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
@@ -63,6 +72,12 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
         ctypes.c_void_p]),
+    "tocvp_split_conv_weights_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv5x5_bf16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
     "tocvp_slot_init_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -147,11 +162,55 @@ def _dev_f32(t, name):
 
 
 # --------------------------------------------------------------------------------------------
+# GEMM arithmetic mode: "fp32" (exact fp32 MFMA), "bf16x3" or "bf16x6" (split-bf16 operands)
+# --------------------------------------------------------------------------------------------
+_GEMM_PRECISION = "fp32"
+_NSPLIT = {"bf16x3": 2, "bf16x6": 3}
+_SPLIT_CACHE = {}
+
+
+class gemm_precision:
+    """ context manager selecting the arithmetic of ``linear`` calls issued inside it """
+
+    def __init__(self, mode):
+        if mode not in ("fp32", "bf16x3", "bf16x6"):
+            raise ValueError(f"unknown GEMM precision {mode!r}")
+        self.mode = mode
+
+    def __enter__(self):
+        global _GEMM_PRECISION
+        self.prev, _GEMM_PRECISION = _GEMM_PRECISION, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global _GEMM_PRECISION
+        _GEMM_PRECISION = self.prev
+
+
+def _split_weight(w, nsplit):
+    """ (N, K) fp32 -> cached (N, nsplit, K) bf16 planes (rebuilt if the weight changes) """
+    key = (id(w), nsplit)
+    hit = _SPLIT_CACHE.get(key)
+    # the weakref guards against id()/address reuse after the original weight was freed
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        return hit[2]
+    if len(_SPLIT_CACHE) > 4096:
+        for k_ in [k_ for k_, v in _SPLIT_CACHE.items() if v[0]() is None]:
+            del _SPLIT_CACHE[k_]
+    N, K = w.shape
+    out = torch.empty((N, nsplit, K), device=w.device, dtype=torch.bfloat16)
+    _check(lib().tocvp_split_weights_bf16(_ptr(w), _ptr(out), N, K, nsplit, _stream()),
+           "tocvp_split_weights_bf16")
+    _SPLIT_CACHE[key] = (weakref.ref(w), (w._version, w.data_ptr()), out)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # tensor-level wrappers
 # --------------------------------------------------------------------------------------------
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_div=1, rv_flip=False,
-           out=None):
+           out=None, precision=None):
     """
     y = act(x W^T + bias + rowvec[idx(row)]) + residual over the last axis of ``x``.
     x: (..., K) contiguous, weight: (N, K) in nn.Linear layout.
@@ -175,9 +234,17 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
     if rowvec is not None:
         assert rowvec.is_contiguous() and rowvec.shape[-1] == N
         rv_mod = rowvec.numel() // N
-    _check(lib().tocvp_gemm_f32(_ptr(x2), K, _ptr(w), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
-                                int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out), N, M, N, K,
-                                int(act), _stream()), "tocvp_gemm_f32")
+    nsplit = _NSPLIT.get(_GEMM_PRECISION if precision is None else precision, 0)
+    if nsplit and K % 32 == 0:
+        ws = _split_weight(w, nsplit)
+        _check(lib().tocvp_gemm_bf16split_f32(_ptr(x2), K, _ptr(ws), nsplit, _ptr(bias), _ptr(r2), N,
+                                              _ptr(rowvec), int(rv_div), int(rv_mod),
+                                              int(bool(rv_flip)), _ptr(out), N, M, N, K, int(act),
+                                              _stream()), "tocvp_gemm_bf16split_f32")
+    else:
+        _check(lib().tocvp_gemm_f32(_ptr(x2), K, _ptr(w), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
+                                    int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out), N, M, N,
+                                    K, int(act), _stream()), "tocvp_gemm_f32")
     return out.reshape(*x.shape[:-1], N)
 
 
@@ -368,4 +435,44 @@ def slot_init(mu, sigma, noise):
     out = torch.empty_like(noise)
     _check(lib().tocvp_slot_init_f32(_ptr(mu), _ptr(sigma), _ptr(noise), _ptr(out),
                                      noise.numel() // D, D, _stream()), "tocvp_slot_init_f32")
+    return out
+
+
+def split_conv_weights_bf16(w):
+    """ (Cout, Cin, 5, 5) fp32 -> (25, Cout, 2*Cin) bf16: [hi | lo] split operands """
+    Cout, Cin = w.shape[:2]
+    out = torch.empty((25, Cout, 2 * Cin), device=w.device, dtype=torch.bfloat16)
+    _check(lib().tocvp_split_conv_weights_bf16(_ptr(w.contiguous()), _ptr(out), Cout, Cin,
+                                               _stream()), "tocvp_split_conv_weights_bf16")
+    return out
+
+
+def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None):
+    """
+    64->64 5x5 conv with split-bf16 (bf16x3) operands, fp32 NHWC in/out.
+    collapsed=(cpos, S): layer-1 mode fed by the analytically collapsed decoder layer 0.
+    """
+    if collapsed is not None:
+        cpos, S = collapsed
+        H, W, Cin = cpos.shape
+        n = S.shape[0]
+        assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
+        xin, aux, mode, dev = cpos, S, 1, cpos.device
+    else:
+        n, H, W, Cin = x.shape
+        assert x.is_contiguous()
+        xin, aux, mode, dev = x, None, 0, x.device
+    Cout = wsplit.shape[1]
+    assert wsplit.dtype == torch.bfloat16 and wsplit.shape == (25, Cout, 2 * Cin)
+    if out is None:
+        out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
+
+    def run():
+        _check(lib().tocvp_conv5x5_bf16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wsplit), _ptr(bias),
+                                              _ptr(out), n, H, W, Cin, Cout, int(bool(relu)),
+                                              _stream()), "tocvp_conv5x5_bf16x3_f32")
+    if TIMER is not None:
+        TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
+    else:
+        run()
     return out

@@ -3,6 +3,8 @@ Slot decoders.  Reference: models/EncodersDecoders/decoders.py (get_decoder :20-
 ConvDecoder :52-125).
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -58,11 +60,19 @@ class ConvDecoder(nn.Module):
         self.decoder = nn.Sequential(*mods)
         self._derived = Derived()
         self.max_slot_images = 2048          # slot images decoded per chunk (bounds HBM scratch)
+        # arithmetic of the 64->64 convs: "fp32" (exact fp32 MFMA) or "bf16x3" (split-bf16 operands
+        # on the bf16 matrix cores, ~2^-16 per-product error, 5.3x fewer matrix cycles)
+        self.conv_precision = os.environ.get("TOCVP_DECODER_PRECISION", "bf16x3")
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
         conv = self.decoder[i].conv
         return self._derived.get(f"wp{i}", [conv.weight], lambda: K.pack_conv_weights(conv.weight))
+
+    def _split(self, i):
+        conv = self.decoder[i].conv
+        return self._derived.get(f"ws{i}", [conv.weight],
+                                 lambda: K.split_conv_weights_bf16(conv.weight))
 
     def _collapsed_layer0(self, pos_table):
         """ (cpos (H,W,C0), tapsum (25*C0, D)) for the current weights / position table """
@@ -105,7 +115,12 @@ class ConvDecoder(nn.Module):
                 if out is None or out.shape != (n, H, W, co):
                     out = torch.empty((n, H, W, co), device=dev, dtype=torch.float32)
                     bufs[which] = out
-                if i == 1:
+                split = (self.conv_precision == "bf16x3" and conv.weight.shape[0] == 64
+                         and conv.weight.shape[1] == 64)
+                if split:
+                    x = K.conv5x5_bf16x3(x, self._split(i), conv.bias, relu=True, out=out,
+                                         collapsed=(cpos, S) if i == 1 else None)
+                elif i == 1:
                     x = K.conv5x5_collapsed(cpos, S, self._packed(1), conv.bias, relu=True, out=out)
                 else:
                     x = K.conv5x5(x, self._packed(i), conv.bias, relu=True, out=out)

@@ -3,6 +3,8 @@ Text-conditioned object-centric predictor.  Reference: models/Predictors/text_co
 (BaseTextOCVP :21-119, forward :79-105; TextOCVP_CustomTF :123-137).
 """
 
+import os
+
 import torch.nn as nn
 
 from ... import kernels as K
@@ -48,6 +50,8 @@ class BaseTextOCVP(nn.Module):
         self.pe = TemporalPositionalEncoding(d_model=self.token_dim,
                                              max_len=self.input_buffer_size + 1, mode="learned")
         self._text_cache = None
+        # arithmetic of the predictor GEMMs: "fp32" | "bf16x3" | "bf16x6" (kernels.gemm_precision)
+        self.gemm_precision = os.environ.get("TOCVP_PREDICTOR_PRECISION", "bf16x6")
 
     def _instantiate_text_encoder(self):
         raise NotImplementedError("'BaseTextOCVP' does not implement '_instantiate_text_encoder'...")
@@ -57,7 +61,8 @@ class BaseTextOCVP(nn.Module):
         c = self._text_cache
         if c is not None and c[0] is text_embeddings and c[1] == text_embeddings._version:
             return c[2]
-        kv = [blk.cross_attention.project_text(text_embeddings) for blk in self.predictor]
+        with K.gemm_precision(self.gemm_precision):
+            kv = [blk.cross_attention.project_text(text_embeddings) for blk in self.predictor]
         self._text_cache = (text_embeddings, text_embeddings._version, kv)
         return kv
 
@@ -67,14 +72,15 @@ class BaseTextOCVP(nn.Module):
         B, w, Ks, D = slots.shape
         slots = slots.contiguous()
         text_kv = self.prepare_text(text_embeddings)
-        tokens = K.linear(slots, self.mlp_in.weight, self.mlp_in.bias,
-                          rowvec=self.pe.rows(w, slots.device), rv_div=Ks, rv_flip=True)
-        tokens = tokens.reshape(B, w * Ks, self.token_dim)
-        for blk, kv in zip(self.predictor, text_kv):
-            tokens = blk(tokens, text_embeddings, text_kv=kv)
-        last = tokens.reshape(B, w, Ks, self.token_dim)[:, -1].contiguous()
-        return K.linear(last, self.mlp_out.weight, self.mlp_out.bias,
-                        residual=slots[:, -1].contiguous() if self.residual else None)
+        with K.gemm_precision(self.gemm_precision):
+            tokens = K.linear(slots, self.mlp_in.weight, self.mlp_in.bias,
+                              rowvec=self.pe.rows(w, slots.device), rv_div=Ks, rv_flip=True)
+            tokens = tokens.reshape(B, w * Ks, self.token_dim)
+            for blk, kv in zip(self.predictor, text_kv):
+                tokens = blk(tokens, text_embeddings, text_kv=kv)
+            last = tokens.reshape(B, w, Ks, self.token_dim)[:, -1].contiguous()
+            return K.linear(last, self.mlp_out.weight, self.mlp_out.bias,
+                            residual=slots[:, -1].contiguous() if self.residual else None)
 
 
 class TextOCVP_CustomTF(BaseTextOCVP):
