@@ -78,6 +78,20 @@ int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsplit, int ns
                              const float* rowvec, int rv_div, int rv_mod, int rv_flip,
                              float* C, int ldc, int M, int N, int K, int act, void* stream);
 
+/* Variant with the weight stored in MFMA-fragment order Wf[n/32][k/16][plane][lane] (16 B per lane,
+ * tocvp_split_weights_frag_bf16): B fragments are fetched straight from L2 with coalesced 1 KiB
+ * loads and never pass through LDS.  Requires K % 64 == 0 and N % 32 == 0. */
+int tocvp_split_weights_frag_bf16(const float* w, void* out, int N, int K, int nsplit, void* stream);
+int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wfrag, int nsplit,
+                             const float* bias, const float* R, int ldr,
+                             const float* rowvec, int rv_div, int rv_mod, int rv_flip,
+                             void* C, int c_split, int ldc, int M, int N, int K, int act,
+                             void* stream);
+/*   a_split != 0: A is already split by its producer, (M, nsplit, K) bf16 planes (lda ignored);
+ *   c_split != 0: C is written as (M, nsplit, N) bf16 planes for a following split GEMM
+ *   (ldc ignored).  Splitting an activation once in its producer instead of once per column block
+ *   of every consumer removes the VALU work that bounded the in-kernel split. */
+
 /* ---------------------------------------------------------------------------------------------
  * y[r,:] = LayerNorm(x[r,:] + add[r % add_rows,:]) * gamma + beta      (biased variance, eps)
  * Replaces nn.LayerNorm at attention.py:49-51,361-362,427,435-436, SAVi.py:116 and
@@ -86,6 +100,10 @@ int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsplit, int ns
  * ------------------------------------------------------------------------------------------- */
 int tocvp_layernorm_f32(const float* x, const float* add, int add_rows, const float* gamma,
                         const float* beta, float* y, int rows, int D, float eps, void* stream);
+/* same, output written as (rows, nsplit, D) bf16 planes (nsplit 2 or 3) for a split-bf16 GEMM */
+int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows, const float* gamma,
+                               const float* beta, void* ysplit, int nsplit, int rows, int D,
+                               float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention  O = softmax(Q K^T * scale [+ key-padding mask]) V        (fp32 MFMA,
@@ -101,6 +119,10 @@ int tocvp_layernorm_f32(const float* x, const float* add, int add_rows, const fl
 int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                   float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                   const int32_t* key_len, void* stream);
+/* same, O written as (B*Tq, nsplit, H*dh) bf16 planes (nsplit 2 or 3) for a split-bf16 GEMM */
+int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                         void* Osplit, int nsplit, int B, int H, int Tq, int Tk, int dh, float scale,
+                         const int32_t* key_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One slot-attention iteration over the feature grid (the north-star kernel), attention.py:99-103:

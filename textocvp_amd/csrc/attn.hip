@@ -22,7 +22,10 @@ struct MhaArgs {
     int B, H, Tq, Tk;
     float scale;
     const int32_t* key_len;
+    void* Osplit; int nsplit;      // optional (B*Tq, nsplit, H*dh) bf16-plane output instead of O
 };
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
     const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + head * DH;
     const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
     const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + head * DH;
-    float* Ob = p.O + (size_t)b * p.Tq * p.ldo + head * DH;
+    float* Ob = p.O ? p.O + (size_t)b * p.Tq * p.ldo + head * DH : nullptr;
 
     int kv_len = p.Tk;
     if (p.key_len) {
@@ -145,28 +148,45 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         for (int i = lane; i < 32 * F4; i += 64) {
             const int r = i / F4, c = (i % F4) * 4;
             const int q = q0 + wave * 32 + r;
-            if (q < p.Tq)
-                *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + c) =
-                    *reinterpret_cast<const f32x4*>(os + r * QS + c);
+            if (q >= p.Tq) continue;
+            f32x4 o = *reinterpret_cast<const f32x4*>(os + r * QS + c);
+            if (p.Osplit == nullptr) {
+                *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + c) = o;
+            } else {
+                const int E = p.H * DH;
+                __bf16* ys = static_cast<__bf16*>(p.Osplit) +
+                             ((size_t)b * p.Tq + q) * p.nsplit * E + head * DH + c;
+                for (int sp = 0; sp < p.nsplit; ++sp) {
+                    bf16x4 piece;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        piece[u] = (__bf16)o[u];
+                        o[u] -= (float)piece[u];
+                    }
+                    *reinterpret_cast<bf16x4*>(ys + (size_t)sp * E) = piece;
+                }
+            }
         }
     }
 }
 
 }  // namespace
 
-extern "C" int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V,
-                             int ldv, float* O, int ldo, int B, int H, int Tq, int Tk, int dh,
-                             float scale, const int32_t* key_len, void* stream) {
-    TOCVP_CHECK_ARG(Q && K && V && O);
+static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                      float* O, int ldo, void* Osplit, int nsplit, int B, int H, int Tq, int Tk,
+                      int dh, float scale, const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Q && K && V && (O || Osplit));
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq > 0 && Tk > 0);
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
-    TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh);
+    TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && (Osplit || ldo >= H * dh));
     TOCVP_CHECK_ARG(B <= 65535 && H <= 65535);
-    if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || !tocvp_aligned16(Q) ||
-        !tocvp_aligned16(K) || !tocvp_aligned16(V) || !tocvp_aligned16(O))
+    TOCVP_CHECK_ARG(Osplit == nullptr || nsplit == 2 || nsplit == 3);
+    if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (O && (ldo & 3)) || !tocvp_aligned16(Q) ||
+        !tocvp_aligned16(K) || !tocvp_aligned16(V) || (O && !tocvp_aligned16(O)) ||
+        (Osplit && !tocvp_aligned16(Osplit)))
         return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
-    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len};
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit};
     dim3 grid((Tq + 127) / 128, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dh == 64)
@@ -174,4 +194,19 @@ extern "C" int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, c
     else
         hipLaunchKernelGGL(mha_f32_kernel<32>, grid, dim3(256), 0, s, p);
     return tocvp_launch_status();
+}
+
+extern "C" int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V,
+                             int ldv, float* O, int ldo, int B, int H, int Tq, int Tk, int dh,
+                             float scale, const int32_t* key_len, void* stream) {
+    return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, Tq, Tk, dh, scale, key_len,
+                      stream);
+}
+
+extern "C" int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V,
+                                    int ldv, void* Osplit, int nsplit, int B, int H, int Tq, int Tk,
+                                    int dh, float scale, const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Osplit != nullptr);
+    return mha_launch(Q, ldq, K, ldk, V, ldv, nullptr, 0, Osplit, nsplit, B, H, Tq, Tk, dh, scale,
+                      key_len, stream);
 }

@@ -13,6 +13,9 @@
 // 4-wave workgroup, halo tile staged once, per-tap weight slices double buffered.  LDS image per
 // pixel / per output channel: [64 hi bf16 | 64 lo bf16 | 16 B pad] = 272 B, so the 16 rows of
 // every ds_read_b128 lane group land on 16 distinct 16-byte slots.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -22,7 +25,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 32, IH = TH + 4, IW = TW + 4;
 constexpr int C = 64;
-constexpr int ROWB = 2 * C * 2 + 16;   // 272 bytes per pixel / per output channel
 
 struct ConvArgs {
     const float* x; const float* aux; const unsigned char* wsplit; const float* bias; float* y;
@@ -45,92 +47,136 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void conv5x5_bf16x3_kernel(ConvArgs p) {
+// NW = waves per workgroup: 4 (one per SIMD, each 2 rows x 64 channels) or 8 (two per SIMD, each
+// 2 rows x 32 channels -- the partner wave's MFMAs cover this wave's barrier / LDS latency).
+// CCH = input channels resident per pass (64: one pass, 152 KB LDS, 1 workgroup / CU;
+//       32: two passes over the taps, 80.6 KB LDS -> 2 workgroups / CU, so one workgroup's tile
+//       staging / epilogue / barriers overlap the other's MFMAs).
+template <int MODE, int NW, int CCH>
+__global__ __launch_bounds__(NW * 64, (CCH == 32 ? 2 : 1) * (NW / 4))
+void conv5x5_bf16x3_kernel(ConvArgs p) {
+    constexpr int NT = NW * 64;            // threads
+    constexpr int NB = 8 / NW;             // 32-channel output blocks per wave (2 or 1)
+    constexpr int ROWB = 2 * CCH * 2 + 16; // LDS bytes per pixel / per output channel (hi | lo | pad)
+    constexpr int NPASS = C / CCH;
+    constexpr int WCHUNKS = C * (CCH / 4); // 16-byte weight chunks per tap per pass
+    constexpr int WR = WCHUNKS / NT;       // per thread
+    constexpr int CPR = CCH / 4;           // 16-byte chunks per weight row (hi + lo)
     __shared__ __attribute__((aligned(16))) unsigned char lds[IH * IW * ROWB + 2 * C * ROWB];
     unsigned char* in_s = lds;
     unsigned char* w_s = lds + IH * IW * ROWB;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
+    const int wrow = (NW == 4) ? wave : (wave >> 1);      // row pair of the tile
+    const int wcol = (NW == 4) ? 0 : (wave & 1);          // first 32-channel block
     const int tiles_x = p.W / TW, tiles = tiles_x * (p.H / TH);
     const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // per-tap weight slice: 64 output channels x 256 B (hi | lo) = 1024 16-byte chunks
-    f32x4 wreg[4];
-    auto wload = [&](int tap) {
+    f32x4 wreg[WR];
+    auto wload = [&](int tap, int pass) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            wreg[i] = *reinterpret_cast<const f32x4*>(p.wsplit + ((size_t)tap * C * 256) +
-                                                      (size_t)(t + 256 * i) * 16);
+        for (int i = 0; i < WR; ++i) {
+            const int idx = t + NT * i;
+            const int co = idx / CPR, part = idx % CPR;
+            const int plane = part / (CPR / 2), sub = part % (CPR / 2);
+            wreg[i] = *reinterpret_cast<const f32x4*>(p.wsplit + ((size_t)tap * C + co) * 256 +
+                                                      plane * 128 + pass * CCH * 2 + sub * 16);
+        }
     };
     auto wstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = t + 256 * i;
-            *reinterpret_cast<f32x4*>(w_s + buf * C * ROWB + (idx >> 4) * ROWB + (idx & 15) * 16) =
+        for (int i = 0; i < WR; ++i) {
+            const int idx = t + NT * i;
+            const int co = idx / CPR, part = idx % CPR;
+            const int plane = part / (CPR / 2), sub = part % (CPR / 2);
+            *reinterpret_cast<f32x4*>(w_s + buf * C * ROWB + co * ROWB + plane * CCH * 2 + sub * 16) =
                 wreg[i];
         }
     };
 
-    wload(0);
-    // ---- halo tile: fp32 -> (hi, lo) bf16 planes in LDS
-    for (int i = t; i < IH * IW * (C / 4); i += 256) {
-        const int pix = i / (C / 4), c = (i % (C / 4)) * 4;
-        const int iy = ty0 + pix / IW - 2, ix = tx0 + pix % IW - 2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            if (MODE == 0) {
-                v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * p.H + iy) * p.W + ix) * C + c);
-            } else {
-                const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
-                v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)iy * p.W + ix) * C + c) +
-                    *reinterpret_cast<const f32x4*>(p.aux + ((size_t)img * 25 + cls) * C + c);
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass > 0) __syncthreads();          // everyone done with the previous pass's LDS images
+    wload(0, pass);
+    // ---- halo tile: fp32 -> (hi, lo) bf16 planes in LDS.
+    // All global loads of the tile are issued back to back from clamped (always valid) addresses
+    // and only then converted: a load-use-per-iteration loop would expose the full memory latency
+    // NIT times per tile (measured: ~40 % of the kernel).
+    constexpr int NIT = (IH * IW * (CCH / 4) + NT - 1) / NT;
+    f32x4 tv[NIT];
+    f32x4 ts[MODE == 1 ? NIT : 1];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(t + it * NT, IH * IW * (CCH / 4) - 1);
+        const int pix = i / (CCH / 4), c = pass * CCH + (i % (CCH / 4)) * 4;
+        const int iy = min(max(ty0 + pix / IW - 2, 0), p.H - 1);
+        const int ix = min(max(tx0 + pix % IW - 2, 0), p.W - 1);
+        if (MODE == 0) {
+            tv[it] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * p.H + iy) * p.W + ix) * C + c);
+        } else {
+            const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
+            tv[it] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)iy * p.W + ix) * C + c);
+            ts[it] = *reinterpret_cast<const f32x4*>(p.aux + ((size_t)img * 25 + cls) * C + c);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = t + it * NT;
+        if (i < IH * IW * (CCH / 4)) {
+            const int pix = i / (CCH / 4), c = (i % (CCH / 4)) * 4;   // channel inside the pass
+            const int iy = ty0 + pix / IW - 2, ix = tx0 + pix % IW - 2;
+            const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            f32x4 v = tv[it];
+            if (MODE == 1) {
+                v += ts[it];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
+            bf16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + c * 2) = hi;
+            *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + CCH * 2 + c * 2) = lo;
         }
-        bf16x4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + c * 2) = hi;
-        *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + C * 2 + c * 2) = lo;
     }
     wstore(0);
     __syncthreads();
 
     for (int tap = 0; tap < 25; ++tap) {
         const int buf = tap & 1;
-        if (tap + 1 < 25) wload(tap + 1);
+        if (tap + 1 < 25) wload(tap + 1, pass);
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it)
         const int dy = tap / 5, dx = tap % 5;
-        const unsigned char* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * ROWB + h * 16;
-        const unsigned char* b_base = w_s + buf * C * ROWB + l31 * ROWB + h * 16;
+        const unsigned char* a_base = in_s + ((2 * wrow + dy) * IW + l31 + dx) * ROWB + h * 16;
+        const unsigned char* b_base = w_s + buf * C * ROWB + (wcol * 32 + l31) * ROWB + h * 16;
 #pragma unroll
-        for (int ks = 0; ks < C / 16; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+        for (int ks = 0; ks < CCH / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 ah[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32);
-                al[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32 + C * 2);
+                al[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32 + CCH * 2);
             }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NB; ++n) {
                 bh[n] = *reinterpret_cast<const bf16x8*>(b_base + n * 32 * ROWB + ks * 32);
-                bl[n] = *reinterpret_cast<const bf16x8*>(b_base + n * 32 * ROWB + ks * 32 + C * 2);
+                bl[n] = *reinterpret_cast<const bf16x8*>(b_base + n * 32 * ROWB + ks * 32 + CCH * 2);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
+                for (int n = 0; n < NB; ++n) {
                     acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
                     acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
                     acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
@@ -139,14 +185,15 @@ __global__ __launch_bounds__(256) void conv5x5_bf16x3_kernel(ConvArgs p) {
         if (tap + 1 < 25) wstore(buf ^ 1);
         __syncthreads();
     }
+  }  // pass
 
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const float bv = p.bias[n * 32 + l31];
+    for (int n = 0; n < NB; ++n) {
+        const float bv = p.bias[(wcol + n) * 32 + l31];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int oy = ty0 + 2 * wave + m;
-            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C + n * 32 + l31;
+            const int oy = ty0 + 2 * wrow + m;
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C + (wcol + n) * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[m][n][r] + bv;
@@ -199,9 +246,29 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
     ConvArgs a{x, aux, static_cast<const unsigned char*>(wsplit), bias, y, nimg, H, W, relu};
     const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (in_mode == 0)
-        hipLaunchKernelGGL(conv5x5_bf16x3_kernel<0>, grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(conv5x5_bf16x3_kernel<1>, grid, dim3(256), 0, s, a);
+    // variants: "8x64" (8 waves, one pass, 1 workgroup/CU), "4x64", "4x32" / "8x32" (two channel
+    // passes, 80.6 KB LDS, 2 workgroups/CU).  Default chosen by measurement.
+    static const int variant = []() {
+        const char* e = getenv("TOCVP_CONV_VARIANT");
+        if (!e) return 432;
+        if (!strcmp(e, "8x64")) return 864;
+        if (!strcmp(e, "4x64")) return 464;
+        if (!strcmp(e, "8x32")) return 832;
+        return 432;
+    }();
+#define TOCVP_LAUNCH_CONV(NW_, CCH_)                                                              \
+    do {                                                                                          \
+        if (in_mode == 0)                                                                         \
+            hipLaunchKernelGGL((conv5x5_bf16x3_kernel<0, NW_, CCH_>), grid, dim3(NW_ * 64), 0, s, a); \
+        else                                                                                      \
+            hipLaunchKernelGGL((conv5x5_bf16x3_kernel<1, NW_, CCH_>), grid, dim3(NW_ * 64), 0, s, a); \
+    } while (0)
+    switch (variant) {
+        case 864: TOCVP_LAUNCH_CONV(8, 64); break;
+        case 464: TOCVP_LAUNCH_CONV(4, 64); break;
+        case 832: TOCVP_LAUNCH_CONV(8, 32); break;
+        default: TOCVP_LAUNCH_CONV(4, 32); break;
+    }
+#undef TOCVP_LAUNCH_CONV
     return tocvp_launch_status();
 }

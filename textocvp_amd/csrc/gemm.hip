@@ -56,31 +56,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int lc = (t & 7) * 4;   // 0,4,..,28
 
     f32x4 ra[RA], rb[RB];
+    float kmask = 1.f;            // zeroes the k-tail of the tile fetched last (applied in lstore)
     auto gload = [&](int k0) {
+        // UNCONDITIONAL loads from clamped (always valid) addresses: rows >= M / N produce values
+        // that are never stored; the k-tail (K % 32 != 0) is zeroed by a multiply.  A predicated
+        // load sits behind a branch, which makes hipcc's s_waitcnt insertion under-count the loads
+        // in flight and stall the MFMAs on the prefetch that was just issued.
+        const int kc = min(k0 + lc, p.K - 4);
+        kmask = (k0 + lc < p.K) ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int row = m0 + lr + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < p.M && k0 + lc < p.K)
-                v = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + k0 + lc);
-            ra[i] = v;
+            const int row = min(m0 + lr + 32 * i, p.M - 1);
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + kc);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int row = n0 + lr + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < p.N && k0 + lc < p.K)
-                v = *reinterpret_cast<const f32x4*>(p.W + (size_t)row * p.K + k0 + lc);
-            rb[i] = v;
+            const int row = min(n0 + lr + 32 * i, p.N - 1);
+            rb[i] = *reinterpret_cast<const f32x4*>(p.W + (size_t)row * p.K + kc);
         }
     };
+    const bool ktail = (p.K % BK) != 0;   // kernel-uniform
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(As + buf * BM * LS + (lr + 32 * i) * LS + lc) = ra[i];
+            *reinterpret_cast<f32x4*>(As + buf * BM * LS + (lr + 32 * i) * LS + lc) =
+                ktail ? ra[i] * kmask : ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4*>(Bs + buf * BN * LS + (lr + 32 * i) * LS + lc) = rb[i];
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * LS + (lr + 32 * i) * LS + lc) =
+                ktail ? rb[i] * kmask : rb[i];
     };
 
     f32x16 acc[MI][NI];

@@ -10,6 +10,8 @@
 // side of the ABI (tocvp_split_weights_bf16: (N, NS, K) bf16 planes) because it is reused by every
 // row block and every call.  128x128x32 tiles, 4 waves x (64x64), double-buffered LDS; LDS rows are
 // [NS planes of 32 bf16 | 16 B pad] -> 144 B / 208 B strides, conflict-free for ds_read_b128.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -25,9 +27,9 @@ struct GemmArgs {
     const float* rowvec; int rv_div, rv_mod, rv_flip;
     float* C; int ldc;
     int M, N, K, act;
+    int a_split;                 // A is (M, NS, K) bf16 planes (producer already split it)
+    int c_split;                 // write C as (M, NS, N) bf16 planes instead of fp32
 };
-
-constexpr int BK = 32;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
@@ -39,15 +41,22 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NS, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_bf16_split_kernel(GemmArgs p) {
+// NS planes, BM x BN x BK tile, WM x WN per wave, NW waves (4: one per SIMD, 8: two per SIMD so the
+// partner's MFMAs cover this wave's split / LDS-store / barrier phases), MINW = waves per SIMD the
+// register budget must allow (occupancy across workgroups).
+template <int NS, int BM, int BN, int WM, int WN, int BK, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_split_kernel(GemmArgs p) {
+    constexpr int NT = NW * 64;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    constexpr int ROWB = NS * BK * 2 + 16;           // bytes per LDS row
-    constexpr int RA = BM / 32;                      // float4 A loads per thread per tile
-    constexpr int WCH = BN * NS * 4;                 // 16-byte W chunks per tile
-    constexpr int RW = (WCH + 255) / 256;
+    static_assert((BM / WM) * (BN / WN) == NW, "wave grid must cover the tile");
+    constexpr int ROWB = NS * BK * 2 + 16;           // bytes per LDS row (planes + pad)
+    constexpr int AF4 = BK / 4;                      // float4 per A row per k-tile
+    constexpr int RA = (BM * AF4) / NT;              // float4 A loads per thread per tile
+    static_assert((BM * AF4) % NT == 0, "A tile must split evenly");
+    constexpr int PPP = BK / 8;                      // 16-byte parts per plane per row
+    constexpr int WCH = BN * NS * PPP;               // 16-byte W chunks per tile
+    constexpr int RW = (WCH + NT - 1) / NT;
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * ROWB];
     unsigned char* As = lds;
@@ -58,33 +67,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_split_kernel(GemmArgs p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntn = (p.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
-    const int lr = t >> 3, lc = (t & 7) * 4;
+    const int lr = t / AF4, lc = (t % AF4) * 4;
+    constexpr int RSTEP = NT / AF4;                  // rows covered per load pass
 
     f32x4 ra[RA], rw[RW];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int row = m0 + lr + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < p.M) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + k0 + lc);
-            ra[i] = v;
+            // unconditional loads from clamped rows (see gemm_bf16_wfrag_kernel)
+            const int row = min(m0 + lr + RSTEP * i, p.M - 1);
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + k0 + lc);
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const int idx = t + 256 * i;                 // chunk id: row-major (row, plane, part)
-            const int row = idx / (NS * 4), rem = idx % (NS * 4);
-            const int plane = rem >> 2, part = rem & 3;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < WCH && n0 + row < p.N)
-                v = *reinterpret_cast<const f32x4*>(
-                    p.W + ((size_t)(n0 + row) * NS + plane) * p.K + k0 + part * 8);
-            rw[i] = v;
+            const int idx = min(t + NT * i, WCH - 1);    // chunk id: row-major (row, plane, part)
+            const int row = min(n0 + idx / (NS * PPP), p.N - 1), rem = idx % (NS * PPP);
+            const int plane = rem / PPP, part = rem % PPP;
+            rw[i] = *reinterpret_cast<const f32x4*>(
+                p.W + ((size_t)row * NS + plane) * p.K + k0 + part * 8);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            unsigned char* dst = As + buf * BM * ROWB + (lr + 32 * i) * ROWB + lc * 2;
+            unsigned char* dst = As + buf * BM * ROWB + (lr + RSTEP * i) * ROWB + lc * 2;
             f32x4 rem = ra[i];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -99,11 +105,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_split_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const int idx = t + 256 * i;
+            const int idx = t + NT * i;
             if (idx < WCH) {
-                const int row = idx / (NS * 4), rem = idx % (NS * 4);
-                *reinterpret_cast<f32x4*>(Bs + buf * BN * ROWB + row * ROWB + (rem >> 2) * BK * 2 +
-                                          (rem & 3) * 16) = rw[i];
+                const int row = idx / (NS * PPP), rem = idx % (NS * PPP);
+                *reinterpret_cast<f32x4*>(Bs + buf * BN * ROWB + row * ROWB + (rem / PPP) * BK * 2 +
+                                          (rem % PPP) * 16) = rw[i];
             }
         }
     };
@@ -183,6 +189,236 @@ __global__ __launch_bounds__(256) void gemm_bf16_split_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3: W operand bypasses LDS.  The (static) weight is stored once in MFMA-FRAGMENT ORDER
+//     Wf[nb][ks][plane][lane] (16 B each): lane (c = l & 31, h = l >> 5) of block nb, k-step ks holds
+//     W[nb*32 + c][ks*16 + 8h .. +7] of that plane, so a wave fetches a whole B fragment with ONE
+//     fully coalesced 1 KiB global_load_dwordx4 (L2 / L1 resident: weights are a few MB) directly
+//     into the registers the MFMA reads.  That removes half of the LDS write+read traffic (the
+//     ds_write pipe was the limiter of the LDS-staged split kernels) and halves the LDS footprint.
+//     B fragments are prefetched one whole k-tile (2 k-steps) ahead in registers.
+// ------------------------------------------------------------------------------------------------
+template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool ASPLIT>
+__global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs p) {
+    constexpr int BK = 32;
+    constexpr int ACH = BM * NS * 4;                 // 16-byte chunks of a pre-split A tile
+    constexpr int RAS = (ACH + NW * 64 - 1) / (NW * 64);
+    constexpr int NT = NW * 64;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == NW, "wave grid must cover the tile");
+    constexpr int ROWB = NS * BK * 2 + 16;
+    constexpr int AF4 = BK / 4;
+    constexpr int RA = (BM * AF4) / NT;
+    static_assert((BM * AF4) % NT == 0, "A tile must split evenly");
+    constexpr int RSTEP = NT / AF4;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * ROWB];
+    unsigned char* As = lds;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (p.N + BN - 1) / BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so
+    // give every XCD a CONTIGUOUS range of tiles (row-block major): the column blocks that share an
+    // A row panel then hit that XCD's L2 instead of refetching it eight times.  Bijective remap.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const int lr = t / AF4, lc = (t % AF4) * 4;
+    const int KS = p.K / 16;                                // k-steps in total
+    const int NBLK = p.N / 32;
+
+    // All global addresses in the k-loop are  UNIFORM base (SGPR pair, advanced per k-tile on the
+    // scalar unit) + per-lane 32-bit byte offset computed once.  Per-lane 64-bit pointers cost two
+    // VGPRs + a v_lshl_add_u64 per load and pushed the kernel into scratch spills; a spilled
+    // address reload inside the loop is a VMEM op whose s_waitcnt vmcnt(0) drains the whole
+    // prefetch (measured: the k-loop ran 3x slower than its MFMA time).
+    const char* const a_bytes = reinterpret_cast<const char*>(p.A);
+    const char* const w_bytes = reinterpret_cast<const char*>(p.W);
+    constexpr int NRA = ASPLIT ? RAS : RA;
+    unsigned voff_a[NRA];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) {
+        if (ASPLIT) {
+            const int idc = min(t + NT * i, ACH - 1);      // (row, plane, part) row-major, clamped
+            const int rowc = min(m0 + idc / (NS * 4), p.M - 1), remc = idc % (NS * 4);
+            voff_a[i] = (unsigned)(((size_t)rowc * NS + (remc >> 2)) * p.K + (remc & 3) * 8) * 2u;
+        } else {
+            const int rowc = min(m0 + lr + RSTEP * i, p.M - 1);
+            voff_a[i] = (unsigned)((size_t)rowc * p.lda + lc) * 4u;
+        }
+    }
+    unsigned voff_b[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        int nb = (n0 + wn * WN) / 32 + j;
+        nb = nb < NBLK ? nb : NBLK - 1;                    // clamped: never stored if out of range
+        voff_b[j] = (unsigned)(((size_t)nb * KS * NS) * 64 + lane) * 16u;
+    }
+
+    f32x4 ra0[NRA];
+    auto gload_a = [&](f32x4 (&ra)[NRA], int k0) {
+        const char* base = a_bytes + (size_t)k0 * (ASPLIT ? 2 : 4);      // uniform
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(base + voff_a[i]);
+    };
+    auto lstore_a = [&](const f32x4 (&ra)[NRA], int buf) {
+        if (ASPLIT) {
+#pragma unroll
+            for (int i = 0; i < RAS; ++i) {
+                const int idx = t + NT * i;
+                if (idx < ACH) {
+                    const int row = idx / (NS * 4), rem = idx % (NS * 4);
+                    *reinterpret_cast<f32x4*>(As + buf * BM * ROWB + row * ROWB + (rem >> 2) * BK * 2 +
+                                              (rem & 3) * 16) = ra[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                unsigned char* dst = As + buf * BM * ROWB + (lr + RSTEP * i) * ROWB + lc * 2;
+                f32x4 rem = ra[i];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    bf16x4 piece;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        piece[u] = (__bf16)rem[u];
+                        rem[u] -= (float)piece[u];
+                    }
+                    *reinterpret_cast<bf16x4*>(dst + s * BK * 2) = piece;
+                }
+            }
+        }
+    };
+    // B fragments of one k-tile: [ks in tile][column block][plane]
+    auto gload_b = [&](bf16x8 (&b)[2][NI][NS], int kt) {
+        const char* base = w_bytes + (size_t)kt * (2 * NS * 64 * 16);    // uniform
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    b[ks][j][s] = *reinterpret_cast<const bf16x8*>(base + voff_b[j] +
+                                                                   (ks * NS + s) * 64 * 16);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const bf16x8 (&b)[2][NI][NS], int buf) {
+        const unsigned char* a_base = As + buf * BM * ROWB + (wm * WM + l31) * ROWB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[MI][NS];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    a[i][s] = *reinterpret_cast<const bf16x8*>(a_base + i * 32 * ROWB + s * BK * 2 +
+                                                               ks * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int sa = 0; sa <= sum; ++sa)
+                            acc[i][j] = mfma_bf16(a[i][sa], b[ks][j][sum - sa], acc[i][j]);
+        }
+    };
+
+    const int nk = p.K / BK;
+    bf16x8 b0[2][NI][NS], b1[2][NI][NS];
+    // Branch-free software pipeline (nk even, host-checked; prefetch indices clamped so the tail
+    // re-fetches tile nk-1): A one k-tile ahead (registers -> LDS), weight fragments one k-tile
+    // ahead in registers, two k-tiles per iteration so the register sets have static names.
+    gload_a(ra0, 0);
+    gload_b(b0, 0);
+    lstore_a(ra0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        const int k1 = min(kt + 1, nk - 1), k2 = min(kt + 2, nk - 1);
+        gload_a(ra0, k1 * BK);
+        gload_b(b1, k1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b0, 0);
+        lstore_a(ra0, 1);
+        __syncthreads();
+        gload_a(ra0, k2 * BK);
+        gload_b(b0, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b1, 1);
+        lstore_a(ra0, 0);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + acc_row(r, h);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.rowvec) {
+                    int idx = (row / p.rv_div) % p.rv_mod;
+                    if (p.rv_flip) idx = p.rv_mod - 1 - idx;
+                    v += p.rowvec[(size_t)idx * p.N + col];
+                }
+                v = apply_act(v, p.act);
+                if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                if (p.c_split) {
+                    __bf16* cs = reinterpret_cast<__bf16*>(p.C) + (size_t)row * NS * p.N + col;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const __bf16 piece = (__bf16)v;
+                        cs[(size_t)s * p.N] = piece;
+                        v -= (float)piece;
+                    }
+                } else {
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// W (N, K) fp32 -> fragment-order bf16 planes Wf[nb][ks][plane][lane][8]
+__global__ __launch_bounds__(256) void split_weights_frag_kernel(const float* __restrict__ w,
+                                                                 __bf16* __restrict__ out, long n,
+                                                                 int K, int NS) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long row = i / K;
+    const int k = (int)(i - row * K);
+    const int nb = (int)(row >> 5), c = (int)(row & 31);
+    const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+    const int KS = K / 16;
+    float rem = w[i];
+    for (int s = 0; s < NS; ++s) {
+        const __bf16 piece = (__bf16)rem;
+        out[((((size_t)nb * KS + ks) * NS + s) * 64 + (hh * 32 + c)) * 8 + j] = piece;
+        rem -= (float)piece;
+    }
+}
+
 // W (N, K) fp32 -> (N, NS, K) bf16 planes: plane s holds bf16 of the residual after planes < s
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w,
                                                             __bf16* __restrict__ out, long n, int K,
@@ -199,12 +435,48 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     }
 }
 
-template <int NS, int BM, int BN, int WM, int WN>
+template <int NS, int BM, int BN, int WM, int WN, int BK, int NW, int MINW>
 int launch(const GemmArgs& p, hipStream_t s) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16_split_kernel<NS, BM, BN, WM, WN>), dim3(ntm * ntn), dim3(256), 0, s,
-                       p);
+    hipLaunchKernelGGL((gemm_bf16_split_kernel<NS, BM, BN, WM, WN, BK, NW, MINW>), dim3(ntm * ntn),
+                       dim3(NW * 64), 0, s, p);
     return tocvp_launch_status();
+}
+
+template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW>
+int launch_wfrag(const GemmArgs& p, hipStream_t s) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    if (p.a_split)
+        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, true>),
+                           dim3(ntm * ntn), dim3(NW * 64), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, false>),
+                           dim3(ntm * ntn), dim3(NW * 64), 0, s, p);
+    return tocvp_launch_status();
+}
+
+template <int NS>
+int dispatch_wfrag(const GemmArgs& p, hipStream_t s) {
+    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (big_tiles < 192) return launch_wfrag<NS, 64, 64, 32, 32, 4, 1>(p, s);
+    return launch_wfrag<NS, 128, 128, 64, 64, 4, 2>(p, s);
+}
+
+template <int NS>
+int dispatch(const GemmArgs& p, hipStream_t s) {
+    static const int variant = []() {
+        const char* e = getenv("TOCVP_GEMM_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (big_tiles < 192) return launch<NS, 64, 64, 32, 32, 32, 4, 1>(p, s);
+    switch (variant) {
+        case 1: return launch<NS, 128, 128, 64, 32, 32, 8, 2>(p, s);   // 8 waves, BK 32
+        case 2: return launch<NS, 128, 128, 64, 64, 16, 4, 2>(p, s);   // 4 waves, BK 16, 2 WG/CU
+        case 3: return launch<NS, 128, 128, 64, 32, 16, 8, 4>(p, s);   // 8 waves, BK 16, 2 WG/CU
+        case 4: return launch<NS, 128, 128, 32, 64, 32, 8, 2>(p, s);   // 8 waves (32x64), BK 32
+        default: return launch<NS, 128, 128, 64, 64, 32, 4, 1>(p, s);
+    }
 }
 
 }  // namespace
@@ -225,7 +497,7 @@ extern "C" int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsp
                                         void* stream) {
     TOCVP_CHECK_ARG(A && Wsplit && C);
     TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3);
-    TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK) == 0);
+    TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 32) == 0);
     TOCVP_CHECK_ARG(lda >= K && ldc >= N);
     TOCVP_CHECK_ARG(R == nullptr || ldr >= N);
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
@@ -233,13 +505,39 @@ extern "C" int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsp
     if ((lda & 3) || !tocvp_aligned16(A) || !tocvp_aligned16(Wsplit)) return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
     GemmArgs p{A, lda, static_cast<const __bf16*>(Wsplit), bias, R, ldr, rowvec, rv_div, rv_mod,
-               rv_flip, C, ldc, M, N, K, act};
+               rv_flip, C, ldc, M, N, K, act, 0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (nsplit == 2) {
-        if (big_tiles >= 192) return launch<2, 128, 128, 64, 64>(p, s);
-        return launch<2, 64, 64, 32, 32>(p, s);
-    }
-    if (big_tiles >= 192) return launch<3, 128, 128, 64, 64>(p, s);
-    return launch<3, 64, 64, 32, 32>(p, s);
+    return nsplit == 2 ? dispatch<2>(p, s) : dispatch<3>(p, s);
+}
+
+extern "C" int tocvp_split_weights_frag_bf16(const float* w, void* out, int N, int K, int nsplit,
+                                             void* stream) {
+    TOCVP_CHECK_ARG(w && out && N > 0 && K > 0 && (nsplit == 2 || nsplit == 3));
+    TOCVP_CHECK_ARG((N % 32) == 0 && (K % 32) == 0);
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(split_weights_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out), n, K, nsplit);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wfrag,
+                                        int nsplit, const float* bias, const float* R, int ldr,
+                                        const float* rowvec, int rv_div, int rv_mod, int rv_flip,
+                                        void* C, int c_split, int ldc, int M, int N, int K, int act,
+                                        void* stream) {
+    TOCVP_CHECK_ARG(A && Wfrag && C);
+    TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3);
+    TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0);
+    TOCVP_CHECK_ARG(a_split || lda >= K);
+    TOCVP_CHECK_ARG(c_split || ldc >= N);
+    TOCVP_CHECK_ARG(R == nullptr || ldr >= N);
+    TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
+    TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
+    if ((!a_split && (lda & 3)) || !tocvp_aligned16(A) || !tocvp_aligned16(Wfrag)) return TOCVP_EALIGN;
+    if (M == 0) return TOCVP_OK;
+    GemmArgs p{static_cast<const float*>(A), lda, static_cast<const __bf16*>(Wfrag), bias, R, ldr,
+               rowvec, rv_div, rv_mod, rv_flip, static_cast<float*>(C), ldc, M, N, K, act,
+               a_split ? 1 : 0, c_split ? 1 : 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return nsplit == 2 ? dispatch_wfrag<2>(p, s) : dispatch_wfrag<3>(p, s);
 }

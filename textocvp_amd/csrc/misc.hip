@@ -8,11 +8,15 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row cached in registers (D <= 1024)
 // ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// NSPLIT = 0: fp32 output y (rows, D); NSPLIT = 2/3: y is (rows, NSPLIT, D) bf16 planes
+template <int NSPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ add, int add_rows,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
-                                                        float* __restrict__ y, int rows, int D,
+                                                        void* __restrict__ yv, int rows, int D,
                                                         float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,7 +52,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (c < D) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-            *reinterpret_cast<f32x4*>(y + (size_t)row * D + c) = (v[i] - mean) * rstd * g + b;
+            f32x4 o = (v[i] - mean) * rstd * g + b;
+            if (NSPLIT == 0) {
+                *reinterpret_cast<f32x4*>(static_cast<float*>(yv) + (size_t)row * D + c) = o;
+            } else {
+                __bf16* ys = static_cast<__bf16*>(yv) + (size_t)row * NSPLIT * D + c;
+#pragma unroll
+                for (int sp = 0; sp < (NSPLIT ? NSPLIT : 1); ++sp) {
+                    bf16x4 piece;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        piece[u] = (__bf16)o[u];
+                        o[u] -= (float)piece[u];
+                    }
+                    *reinterpret_cast<bf16x4*>(ys + (size_t)sp * D) = piece;
+                }
+            }
         }
     }
 }
@@ -220,9 +239,29 @@ extern "C" int tocvp_layernorm_f32(const float* x, const float* add, int add_row
         !tocvp_aligned16(beta) || (add && !tocvp_aligned16(add)))
         return TOCVP_EALIGN;
     if (rows == 0) return TOCVP_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, add, add_rows, gamma, beta, y, rows, D,
-                       eps);
+    hipLaunchKernelGGL(layernorm_kernel<0>, dim3(blocks_for(rows, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, add, add_rows, gamma, beta,
+                       static_cast<void*>(y), rows, D, eps);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows,
+                                          const float* gamma, const float* beta, void* ysplit,
+                                          int nsplit, int rows, int D, float eps, void* stream) {
+    TOCVP_CHECK_ARG(x && gamma && beta && ysplit && (nsplit == 2 || nsplit == 3));
+    TOCVP_CHECK_ARG(rows >= 0 && D > 0 && D <= 1024 && (D & 3) == 0);
+    TOCVP_CHECK_ARG(add == nullptr || add_rows > 0);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(ysplit) || !tocvp_aligned16(gamma) ||
+        !tocvp_aligned16(beta) || (add && !tocvp_aligned16(add)))
+        return TOCVP_EALIGN;
+    if (rows == 0) return TOCVP_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nsplit == 2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks_for(rows, 4)), dim3(256), 0, s, x, add,
+                           add_rows, gamma, beta, ysplit, rows, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks_for(rows, 4)), dim3(256), 0, s, x, add,
+                           add_rows, gamma, beta, ysplit, rows, D, eps);
     return tocvp_launch_status();
 }
 

@@ -34,6 +34,21 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p]),
+    "tocvp_split_weights_frag_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_gemm_bf16wfrag_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_layernorm_split_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
+    "tocvp_mha_split_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_layernorm_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
@@ -187,9 +202,33 @@ class gemm_precision:
         _GEMM_PRECISION = self.prev
 
 
-def _split_weight(w, nsplit):
-    """ (N, K) fp32 -> cached (N, nsplit, K) bf16 planes (rebuilt if the weight changes) """
-    key = (id(w), nsplit)
+_WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
+
+
+class SplitAct:
+    """
+    An activation already split into bf16 planes by its producer: ``planes`` is (rows, nsplit, D)
+    bf16, ``shape`` the logical fp32 shape (..., D).  Consumed as the A operand of a split GEMM.
+    """
+
+    __slots__ = ("planes", "shape")
+
+    def __init__(self, planes, shape):
+        self.planes, self.shape = planes, tuple(shape)
+
+    @property
+    def nsplit(self):
+        return self.planes.shape[1]
+
+
+def active_nsplit():
+    """ planes per operand of the GEMM arithmetic selected by the enclosing gemm_precision() """
+    return _NSPLIT.get(_GEMM_PRECISION, 0) if _WFRAG else 0
+
+
+def _split_weight(w, nsplit, frag=False):
+    """ (N, K) fp32 -> cached bf16 planes: (N, nsplit, K) or fragment order (rebuilt on change) """
+    key = (id(w), nsplit, frag)
     hit = _SPLIT_CACHE.get(key)
     # the weakref guards against id()/address reuse after the original weight was freed
     if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
@@ -199,8 +238,12 @@ def _split_weight(w, nsplit):
             del _SPLIT_CACHE[k_]
     N, K = w.shape
     out = torch.empty((N, nsplit, K), device=w.device, dtype=torch.bfloat16)
-    _check(lib().tocvp_split_weights_bf16(_ptr(w), _ptr(out), N, K, nsplit, _stream()),
-           "tocvp_split_weights_bf16")
+    if frag:
+        _check(lib().tocvp_split_weights_frag_bf16(_ptr(w), _ptr(out), N, K, nsplit, _stream()),
+               "tocvp_split_weights_frag_bf16")
+    else:
+        _check(lib().tocvp_split_weights_bf16(_ptr(w), _ptr(out), N, K, nsplit, _stream()),
+               "tocvp_split_weights_bf16")
     _SPLIT_CACHE[key] = (weakref.ref(w), (w._version, w.data_ptr()), out)
     return out
 
@@ -210,22 +253,29 @@ def _split_weight(w, nsplit):
 # --------------------------------------------------------------------------------------------
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_div=1, rv_flip=False,
-           out=None, precision=None):
+           out=None, precision=None, out_split=0):
     """
     y = act(x W^T + bias + rowvec[idx(row)]) + residual over the last axis of ``x``.
-    x: (..., K) contiguous, weight: (N, K) in nn.Linear layout.
+    x: (..., K) contiguous fp32 tensor or a SplitAct; weight: (N, K) in nn.Linear layout.
+    out_split = 2/3: return a SplitAct (bf16 planes) for a following split GEMM.
     """
-    _dev_f32(x, "x"), _dev_f32(weight, "weight")
-    K = x.shape[-1]
-    N = weight.shape[0]
-    assert weight.shape[1] == K, (weight.shape, x.shape)
-    x2 = x.reshape(-1, K)
-    if not x2.is_contiguous():
-        x2 = x2.contiguous()
-    M = x2.shape[0]
+    _dev_f32(weight, "weight")
+    N, K = weight.shape
     w = weight if weight.is_contiguous() else weight.contiguous()
-    if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    pre_split = isinstance(x, SplitAct)
+    if pre_split:
+        assert x.shape[-1] == K, (x.shape, weight.shape)
+        lead, x2, M = x.shape[:-1], x.planes, x.planes.shape[0]
+        nsplit = x.nsplit
+    else:
+        _dev_f32(x, "x")
+        assert x.shape[-1] == K, (weight.shape, x.shape)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        nsplit = _NSPLIT.get(_GEMM_PRECISION if precision is None else precision, 0)
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, N)
@@ -234,8 +284,22 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
     if rowvec is not None:
         assert rowvec.is_contiguous() and rowvec.shape[-1] == N
         rv_mod = rowvec.numel() // N
-    nsplit = _NSPLIT.get(_GEMM_PRECISION if precision is None else precision, 0)
-    if nsplit and K % 32 == 0:
+    frag_ok = nsplit and K % 64 == 0 and N % 32 == 0 and _WFRAG
+    if (pre_split or out_split) and not frag_ok:
+        raise TocvpError("split activations need the fragment-order split GEMM (K, N % 32 == 0)")
+    if out_split:
+        assert out is None and out_split == nsplit
+        out = torch.empty((M, nsplit, N), device=w.device, dtype=torch.bfloat16)
+    elif out is None:
+        out = torch.empty((M, N), device=w.device, dtype=torch.float32)
+    if frag_ok:
+        ws = _split_weight(w, nsplit, frag=True)
+        _check(lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,
+                                              _ptr(bias), _ptr(r2), N, _ptr(rowvec), int(rv_div),
+                                              int(rv_mod), int(bool(rv_flip)), _ptr(out),
+                                              int(bool(out_split)), N, M, N, K, int(act), _stream()),
+               "tocvp_gemm_bf16wfrag_f32")
+    elif nsplit and K % 32 == 0:
         ws = _split_weight(w, nsplit)
         _check(lib().tocvp_gemm_bf16split_f32(_ptr(x2), K, _ptr(ws), nsplit, _ptr(bias), _ptr(r2), N,
                                               _ptr(rowvec), int(rv_div), int(rv_mod),
@@ -245,32 +309,43 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         _check(lib().tocvp_gemm_f32(_ptr(x2), K, _ptr(w), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
                                     int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out), N, M, N,
                                     K, int(act), _stream()), "tocvp_gemm_f32")
-    return out.reshape(*x.shape[:-1], N)
+    if out_split:
+        return SplitAct(out, (*lead, N))
+    return out.reshape(*lead, N)
 
 
-def layer_norm(x, gamma, beta, eps, add=None):
-    """ LayerNorm over the last axis; ``add`` (R, D) is added row-periodically before the norm. """
+def layer_norm(x, gamma, beta, eps, add=None, split=0):
+    """
+    LayerNorm over the last axis; ``add`` (R, D) is added row-periodically before the norm.
+    split = 2/3: return a SplitAct (bf16 planes) instead of an fp32 tensor.
+    """
     _dev_f32(x, "x")
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     rows = x2.shape[0]
-    y = torch.empty_like(x2)
     add_rows = 0
     if add is not None:
         assert add.is_contiguous() and add.shape[-1] == D
         add_rows = add.numel() // D
+    if split:
+        y = torch.empty((rows, split, D), device=x.device, dtype=torch.bfloat16)
+        _check(lib().tocvp_layernorm_split_bf16(_ptr(x2), _ptr(add), add_rows, _ptr(gamma),
+                                                _ptr(beta), _ptr(y), int(split), rows, D, float(eps),
+                                                _stream()), "tocvp_layernorm_split_bf16")
+        return SplitAct(y, x.shape)
+    y = torch.empty_like(x2)
     _check(lib().tocvp_layernorm_f32(_ptr(x2), _ptr(add), add_rows, _ptr(gamma), _ptr(beta),
                                      _ptr(y), rows, D, float(eps), _stream()),
            "tocvp_layernorm_f32")
     return y.reshape(x.shape)
 
 
-def mha(q, k, v, heads, scale, key_len=None):
+def mha(q, k, v, heads, scale, key_len=None, out_split=0):
     """
     q: (B, Tq, E) view with unit last stride (may be a column slice of a fused projection);
-    k, v: (B, Tk, E) likewise.  Returns (B, Tq, E) contiguous.
+    k, v: (B, Tk, E) likewise.  Returns (B, Tq, E) contiguous fp32, or a SplitAct if out_split.
     """
     B, Tq, E = q.shape
     Tk = k.shape[1]
@@ -278,9 +353,16 @@ def mha(q, k, v, heads, scale, key_len=None):
     for name, t in (("q", q), ("k", k), ("v", v)):
         _dev_f32(t, name)
         assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), (name, t.stride())
-    o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
     if key_len is not None:
         assert key_len.dtype == torch.int32 and key_len.is_cuda and key_len.numel() == B
+    if out_split:
+        o = torch.empty((B * Tq, out_split, E), device=q.device, dtype=torch.bfloat16)
+        _check(lib().tocvp_mha_split_bf16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v),
+                                          v.stride(1), _ptr(o), int(out_split), B, heads, Tq, Tk, dh,
+                                          float(scale), _ptr(key_len), _stream()),
+               "tocvp_mha_split_bf16")
+        return SplitAct(o, (B, Tq, E))
+    o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
     _check(lib().tocvp_mha_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1),
                                _ptr(o), E, B, heads, Tq, Tk, dh, float(scale), _ptr(key_len),
                                _stream()), "tocvp_mha_f32")

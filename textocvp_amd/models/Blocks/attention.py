@@ -7,6 +7,8 @@ fp32-MFMA GEMMs with fused bias / ReLU / residual epilogues, one-wave-per-row La
 flash-style fp32-MFMA attention and the location-streaming slot-attention iteration.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,13 +19,30 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
            "TransformerBlock", "TransformerDecoderBlock", "AdaptedEncoderBlock"]
 
 
-def _ln(x, ln, add=None):
-    return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add)
+_PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0") != "0"   # measured slower than in-kernel split
+
+
+def _ln(x, ln, add=None, split=0):
+    return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add, split=split)
+
+
+def _ns(*dims):
+    """
+    planes for split activations under the active GEMM arithmetic (0 = keep fp32 tensors).
+    Activations that only feed GEMMs are emitted by their producer (LayerNorm, GEMM epilogue,
+    attention epilogue) directly as bf16 planes, so each element is split once instead of once
+    per column block of every consuming GEMM.
+    """
+    if not _PRESPLIT:
+        return 0
+    ns = K.active_nsplit()
+    return ns if ns and all(d % 64 == 0 for d in dims) else 0
 
 
 def _mlp(x, seq, residual):
     """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
-    h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU)
+    ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0])
+    h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
     return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
 
 
@@ -151,13 +170,13 @@ class MultiHeadSelfAttention(MetaAttention):
     def forward(self, x, residual=None, **kwargs):
         if kwargs.get("mask", None) is not None:
             raise NotImplementedError("attention masks are not used on the slot-rollout path")
-        E = x.shape[-1]
+        E = x.shape[-1]                                                   # tensor or SplitAct
         w = self._derived.get(
             "w_qkv", [self.q.weight, self.k.weight, self.v.weight],
             lambda: torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous())
         qkv = K.linear(x, w)                                              # (B, T, 3E)
         o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], self.num_heads,
-                  (E // self.num_heads) ** -0.5)
+                  (E // self.num_heads) ** -0.5, out_split=_ns(E))
         return K.linear(o, self.out_projection[0].weight, residual=residual)
 
 
@@ -188,7 +207,8 @@ class MultiHeadCrossAttention(MetaAttention):
             kv = self.project_kv(enc_embs)
         inner = self.q.weight.shape[0]
         q = K.linear(query_embs, self.q.weight)
-        o = K.mha(q, kv[..., :inner], kv[..., inner:], self.num_heads, self.dim_head ** -0.5)
+        o = K.mha(q, kv[..., :inner], kv[..., inner:], self.num_heads, self.dim_head ** -0.5,
+                  out_split=_ns(inner, self.out_projection.weight.shape[0]))
         return K.linear(o, self.out_projection.weight, self.out_projection.bias, residual=residual)
 
 
@@ -215,8 +235,9 @@ class TransformerBlock(nn.Module):
         require_inference(self)
         inputs = inputs.contiguous()
         if self.pre_norm:
-            y = self.attn(_ln(inputs, self.layernorm_query), residual=inputs)
-            return _mlp(_ln(y, self.layernorm_mlp), self.mlp, residual=y)
+            E = self.embed_dim
+            y = self.attn(_ln(inputs, self.layernorm_query, split=_ns(E)), residual=inputs)
+            return _mlp(_ln(y, self.layernorm_mlp, split=_ns(E, self.mlp_size)), self.mlp, residual=y)
         y = _ln(self.attn(inputs, residual=inputs), self.layernorm_query)
         return _ln(_mlp(y, self.mlp, residual=y), self.layernorm_mlp)
 
@@ -242,9 +263,11 @@ class TransformerDecoderBlock(nn.Module):
         assert queries.ndim == 3
         if text_kv is None:
             text_kv = self.project_text(feats)
-        z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q), residual=queries,
-                            kv=text_kv)
-        return _mlp(_ln(z, self.ln_mlp), self.mlp, residual=z)
+        E = queries.shape[-1]
+        z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q, split=_ns(E)),
+                            residual=queries, kv=text_kv)
+        return _mlp(_ln(z, self.ln_mlp, split=_ns(E, self.mlp[0].weight.shape[0])), self.mlp,
+                    residual=z)
 
 
 class AdaptedEncoderBlock(TransformerBlock):
@@ -262,9 +285,10 @@ class AdaptedEncoderBlock(TransformerBlock):
 
     def forward(self, x, text_embeddings, text_kv=None):
         assert x.ndim == 3, f"Input 'x' must have 3 dims, but got {x.shape = }..."
-        y = self.attn(_ln(x, self.layernorm_query), residual=x)
+        E = self.embed_dim
+        y = self.attn(_ln(x, self.layernorm_query, split=_ns(E)), residual=x)
         z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
-        return _mlp(_ln(z, self.layernorm_mlp), self.mlp, residual=y)
+        return _mlp(_ln(z, self.layernorm_mlp, split=_ns(E, self.mlp_size)), self.mlp, residual=y)
 
     def condition_slots_given_caption(self, slots_to_condition, text_embeddings, text_kv=None):
         return self.cross_attention(queries=slots_to_condition, feats=text_embeddings,
