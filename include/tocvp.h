@@ -206,11 +206,12 @@ int tocvp_dec_tapsum_f32(const float* w, float* out, int Cout, int Cin, void* st
  * split RGB / alpha, softmax over the K slots, recon = sum_K rgb * mask.
  *   x:(F*K,H,W,Cin) NHWC; w:(4,Cin,3,3) nn.Conv2d layout; bias:(4)
  *   recons_imgs:(F,3,H,W)  recons:(F,K,3,H,W)  masks:(F,K,1,H,W)   (reference output layouts)
- *   K <= 32, Cin == 64, H % 8 == 0, W % 16 == 0.
+ *   K <= 32, Cin == 64, H % 16 == 0, W % 16 == 0.
+ *   ws: >= 9*Cin*4*4 bytes of scratch (weights repacked to [tap][c][4] for scalar-path reads).
  * ------------------------------------------------------------------------------------------- */
 int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias, float* recons_imgs,
                        float* recons, float* masks, int F, int K, int H, int W, int Cin,
-                       void* stream);
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Text-encoder front end (text_encoders.py:89-103): token + position embedding, LayerNorm

@@ -214,18 +214,23 @@ __global__ __launch_bounds__(256) void conv5x5_in3_kernel(const float* __restric
 // decoder tail: conv3x3 (64 -> 4) per slot image, softmax over slots, compositing
 // one thread = one pixel of an 8 x 16 tile, loops over the K slot images of its frame
 // ------------------------------------------------------------------------------------------
-constexpr int DT_H = 8, DT_W = 16, DT_C = 64, DT_CS = DT_C + 4;
+// gfx950 notes: 16 x 16 pixel tile per 256-thread workgroup, input channels in two 32-channel
+// passes (46.7 KB halo tile -> 2 workgroups / CU).  The 3x3x64x4 weights are read with
+// WAVE-UNIFORM indices from a repacked [tap][c][4] table, so hipcc keeps them on the scalar path
+// (s_load + v_fmac with an SGPR operand) instead of spending an LDS broadcast read per FMA group;
+// all global loads of a halo tile are issued back to back before the first conversion.
+constexpr int DT_H = 16, DT_W = 16, DT_C = 64, DT_CC = 32, DT_CS = DT_CC + 4;
+constexpr int DT_IH = DT_H + 2, DT_IW = DT_W + 2;
 
-__global__ __launch_bounds__(128) void dec_tail_kernel(const float* __restrict__ x,
-                                                       const float* __restrict__ w,
-                                                       const float* __restrict__ bias,
-                                                       float* __restrict__ recons_imgs,
-                                                       float* __restrict__ recons,
-                                                       float* __restrict__ masks, int K, int H,
-                                                       int W) {
-    __shared__ __attribute__((aligned(16))) float in_s[(DT_H + 2) * (DT_W + 2) * DT_CS];
-    __shared__ __attribute__((aligned(16))) float w_s[9 * DT_C * 4];
-    __shared__ float alpha_s[32 * 128];
+__global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ wq,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ recons_imgs,
+                                                          float* __restrict__ recons,
+                                                          float* __restrict__ masks, int K, int H,
+                                                          int W) {
+    __shared__ __attribute__((aligned(16))) float in_s[DT_IH * DT_IW * DT_CS];
+    __shared__ float alpha_s[32 * 256];
     const int t = threadIdx.x;
     const int f = blockIdx.y;
     const int tiles_x = W / DT_W;
@@ -233,60 +238,79 @@ __global__ __launch_bounds__(128) void dec_tail_kernel(const float* __restrict__
     const int py = t / DT_W, px = t % DT_W;
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)(ty0 + py) * W + tx0 + px;
-
-    // weights (4, C, 3, 3) -> w_s[tap][c][co]
-    for (int i = t; i < 9 * DT_C * 4; i += 128) {
-        const int co = i / (DT_C * 9), rem = i % (DT_C * 9);
-        const int c = rem / 9, tap = rem % 9;
-        w_s[(tap * DT_C + c) * 4 + co] = w[i];
-    }
     const f32x4 bv = {bias[0], bias[1], bias[2], bias[3]};
 
+    constexpr int F4 = DT_CC / 4;                                   // float4 per pixel per pass
+    constexpr int NIT = (DT_IH * DT_IW * F4 + 255) / 256;           // 11 loads per thread per pass
+
     for (int k = 0; k < K; ++k) {
-        __syncthreads();
         const float* xi = x + ((size_t)f * K + k) * HW * DT_C;
-        for (int i = t; i < (DT_H + 2) * (DT_W + 2) * (DT_C / 4); i += 128) {
-            const int p = i / (DT_C / 4), c = (i % (DT_C / 4)) * 4;
-            const int iy = ty0 + p / (DT_W + 2) - 1, ix = tx0 + p % (DT_W + 2) - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *reinterpret_cast<const f32x4*>(xi + ((size_t)iy * W + ix) * DT_C + c);
-            *reinterpret_cast<f32x4*>(in_s + p * DT_CS + c) = v;
-        }
-        __syncthreads();
         f32x4 acc = bv;
+#pragma unroll 1
+        for (int pass = 0; pass < DT_C / DT_CC; ++pass) {
+            f32x4 tv[NIT];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float* ip = in_s + ((py + tap / 3) * (DT_W + 2) + px + tap % 3) * DT_CS;
-            const float* wp = w_s + tap * DT_C * 4;
-#pragma unroll 4
-            for (int c4 = 0; c4 < DT_C / 4; ++c4) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(ip + 4 * c4);
+            for (int it = 0; it < NIT; ++it) {                      // batched, clamped loads
+                const int i = min(t + it * 256, DT_IH * DT_IW * F4 - 1);
+                const int p = i / F4, c = (i % F4) * 4;
+                const int iy = min(max(ty0 + p / DT_IW - 1, 0), H - 1);
+                const int ix = min(max(tx0 + p % DT_IW - 1, 0), W - 1);
+                tv[it] = *reinterpret_cast<const f32x4*>(xi + ((size_t)iy * W + ix) * DT_C +
+                                                         pass * DT_CC + c);
+            }
+            __syncthreads();                                        // previous pass / slot consumed
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc += xv[u] * *reinterpret_cast<const f32x4*>(wp + (4 * c4 + u) * 4);
+            for (int it = 0; it < NIT; ++it) {
+                const int i = t + it * 256;
+                if (i < DT_IH * DT_IW * F4) {
+                    const int p = i / F4, c = (i % F4) * 4;
+                    const int iy = ty0 + p / DT_IW - 1, ix = tx0 + p % DT_IW - 1;
+                    const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    f32x4 v = tv[it];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
+                    *reinterpret_cast<f32x4*>(in_s + p * DT_CS + c) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* ip = in_s + ((py + tap / 3) * DT_IW + px + tap % 3) * DT_CS;
+                const float* wt = wq + ((size_t)tap * DT_C + pass * DT_CC) * 4;   // wave-uniform
+#pragma unroll
+                for (int c4 = 0; c4 < DT_CC / 4; ++c4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(ip + 4 * c4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* w4 = wt + (4 * c4 + u) * 4;
+                        acc[0] = fmaf(xv[u], w4[0], acc[0]);
+                        acc[1] = fmaf(xv[u], w4[1], acc[1]);
+                        acc[2] = fmaf(xv[u], w4[2], acc[2]);
+                        acc[3] = fmaf(xv[u], w4[3], acc[3]);
+                    }
+                }
             }
         }
         float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
         ro[0] = acc[0];
         ro[HW] = acc[1];
         ro[2 * HW] = acc[2];
-        alpha_s[k * 128 + t] = acc[3];
+        alpha_s[k * 256 + t] = acc[3];
     }
 
     // softmax over slots (exact two-pass, as F.softmax) + compositing
     float m = -1.0e30f;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, alpha_s[k * 128 + t]);
+    for (int k = 0; k < K; ++k) m = fmaxf(m, alpha_s[k * 256 + t]);
     float sum = 0.f;
     for (int k = 0; k < K; ++k) {
-        const float e = expf(alpha_s[k * 128 + t] - m);
-        alpha_s[k * 128 + t] = e;
+        const float e = expf(alpha_s[k * 256 + t] - m);
+        alpha_s[k * 256 + t] = e;
         sum += e;
     }
     const float inv = 1.0f / sum;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     for (int k = 0; k < K; ++k) {
-        const float mk = alpha_s[k * 128 + t] * inv;
+        const float mk = alpha_s[k * 256 + t] * inv;
         masks[((size_t)f * K + k) * HW + pix] = mk;
         const float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
         c0 += ro[0] * mk;
@@ -297,6 +321,15 @@ __global__ __launch_bounds__(128) void dec_tail_kernel(const float* __restrict__
     co[0] = c0;
     co[HW] = c1;
     co[2 * HW] = c2;
+}
+
+// (4, C, 3, 3) -> [tap][c][4] so that the 4 output channels of one (tap, c) are one 16-byte group
+__global__ __launch_bounds__(256) void dec_tail_pack_kernel(const float* __restrict__ w,
+                                                            float* __restrict__ wq, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 9 * C * 4) return;
+    const int co = i & 3, c = (i >> 2) % C, tap = i / (4 * C);
+    wq[i] = w[((size_t)co * C + c) * 9 + tap];
 }
 
 template <int CIN, int COUT>
@@ -346,14 +379,19 @@ extern "C" int tocvp_conv5x5_in3_f32(const float* x, long long img_stride, const
 
 extern "C" int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias,
                                   float* recons_imgs, float* recons, float* masks, int F, int K,
-                                  int H, int W, int Cin, void* stream) {
-    TOCVP_CHECK_ARG(x && w && bias && recons_imgs && recons && masks);
+                                  int H, int W, int Cin, void* ws, size_t ws_bytes, void* stream) {
+    TOCVP_CHECK_ARG(x && w && bias && recons_imgs && recons && masks && ws);
     TOCVP_CHECK_ARG(F >= 0 && F <= 65535 && K > 0 && K <= 32 && Cin == DT_C);
     TOCVP_CHECK_ARG((H % DT_H) == 0 && (W % DT_W) == 0);
-    if (!tocvp_aligned16(x)) return TOCVP_EALIGN;
+    TOCVP_CHECK_ARG(ws_bytes >= (size_t)9 * DT_C * 4 * sizeof(float));
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(ws)) return TOCVP_EALIGN;
     if (F == 0) return TOCVP_OK;
-    hipLaunchKernelGGL(dec_tail_kernel, dim3((H / DT_H) * (W / DT_W), F), dim3(128), 0,
-                       static_cast<hipStream_t>(stream), x, w, bias, recons_imgs, recons, masks, K,
-                       H, W);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* wq = static_cast<float*>(ws);
+    hipLaunchKernelGGL(dec_tail_pack_kernel, dim3((9 * DT_C * 4 + 255) / 256), dim3(256), 0, s, w, wq,
+                       DT_C);
+    if (hipGetLastError() != hipSuccess) return TOCVP_ELAUNCH;
+    hipLaunchKernelGGL(dec_tail_kernel, dim3((H / DT_H) * (W / DT_W), F), dim3(256), 0, s, x,
+                       static_cast<const float*>(wq), bias, recons_imgs, recons, masks, K, H, W);
     return tocvp_launch_status();
 }

@@ -82,7 +82,7 @@ _SIGNATURES = {
     "tocvp_dec_tail_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "tocvp_text_embed_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
@@ -492,9 +492,10 @@ def dec_tail(x, w, bias, F, K, out=None):
         imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
         recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
         masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
+    ws = torch.empty(9 * Cin * 4, device=dev, dtype=torch.float32)
     _check(lib().tocvp_dec_tail_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs),
-                                    _ptr(recons), _ptr(masks), F, K, H, W, Cin, _stream()),
-           "tocvp_dec_tail_f32")
+                                    _ptr(recons), _ptr(masks), F, K, H, W, Cin, _ptr(ws),
+                                    ws.numel() * 4, _stream()), "tocvp_dec_tail_f32")
     return imgs, recons, masks
 
 
