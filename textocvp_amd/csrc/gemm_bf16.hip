@@ -457,8 +457,14 @@ int launch_wfrag(const GemmArgs& p, hipStream_t s) {
 
 template <int NS>
 int dispatch_wfrag(const GemmArgs& p, hipStream_t s) {
+    static const int variant = []() {
+        const char* e = getenv("TOCVP_GEMM_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (big_tiles < 192) return launch_wfrag<NS, 64, 64, 32, 32, 4, 1>(p, s);
+    if (variant == 1 && big_tiles >= 1024) return launch_wfrag<NS, 256, 128, 64, 64, 8, 2>(p, s);
+    if (variant == 2) return launch_wfrag<NS, 128, 128, 64, 32, 8, 2>(p, s);
     return launch_wfrag<NS, 128, 128, 64, 64, 4, 2>(p, s);
 }
 
