@@ -108,13 +108,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")      # RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; TOCVP_DIST_BACKEND=gloo lets several ranks share ONE GPU to rehearse the
+    # torchrun path on a single-GPU box (the collective then runs on host copies of the metrics)
+    backend = os.environ.get("TOCVP_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)     # "nccl" is RCCL on ROCm
 
     from textocvp_amd import kernels, synth
     from textocvp_amd.evaluator import forward_eval, gather_metrics, psnr_per_frame
@@ -160,7 +164,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, kernels.TIMER = kernels.TIMER, None
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -215,3 +215,52 @@ def test_slot_permutation_equivariance(k7):
     b = savi(mode="decomp", x=videos, num_imgs=3, decode=False,
              init_noise=noise[:, perm])["slot_history"]
     assert max_abs(a[:, :, perm].cpu(), b.cpu()) < 5e-5
+
+
+@torch.no_grad()
+def test_rollout_options_against_oracle():
+    """
+    Wrapper options the fixtures do not cover: 3 seed frames, a 4-frame sliding buffer (slides
+    after the second step), teacher forcing (the reference applies the config value in eval mode
+    too, predictor_wrapper.py:136-139) and the num_preds override.
+    """
+    exp = default_exp_params(num_slots=7, num_context=3, num_preds=5, input_buffer_size=4)
+    savi = setup_model(exp["model"]).eval()
+    synth.fill_module_(savi, prefix="savi.")
+    videos = synth.synth_videos(2, 8, seed=41)
+    tokens, lengths = synth.synth_captions(2, max_len=10, lengths=[10, 6], seed=42)
+    noise = synth.synth_noise(2, 7, 128, seed=43)
+    ssd = {k: v.clone() for k, v in savi.state_dict().items()}
+    hist_ref = O.savi_decomp(ssd, videos, noise, 8)
+    savi = savi.to(DEV)
+    hist = savi(mode="decomp", x=gpu(videos), num_imgs=8, decode=False, init_noise=noise)["slot_history"]
+    assert max_abs(hist.cpu(), hist_ref) < 1e-4
+    for tf in (False, True):
+        exp["prediction_params"]["teacher_force"] = tf
+        pred = setup_predictor(exp).eval()
+        synth.fill_module_(pred, prefix="pred.")
+        psd = {k: v.clone() for k, v in pred.state_dict().items()}
+        ref = O.rollout(psd, hist_ref, tokens, lengths, 3, 5, buffer_size=4, teacher_force=tf)
+        pred = pred.to(DEV)
+        got = pred(hist, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths))
+        assert got.shape == (2, 5, 7, 128)
+        assert max_abs(got.cpu(), ref) < 1e-4, f"teacher_force={tf}"
+        got2 = pred(hist, num_preds=2, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths))
+        assert max_abs(got2.cpu(), ref[:, :2]) < 1e-4
+
+
+@torch.no_grad()
+def test_learned_initializer_and_identity_transition():
+    """ the other initialiser / transition choices of the SAVi factory (initializers.py:39-61) """
+    exp = default_exp_params(num_slots=7)
+    exp["model"]["model_params"]["initializer"] = "Learned"
+    exp["model"]["model_params"]["transition_module"] = {"model_name": ""}
+    savi = setup_model(exp["model"]).eval()
+    synth.fill_module_(savi, prefix="savi2.")
+    assert "initializer.slots" in savi.state_dict() and not any(
+        k.startswith("transition_module") for k in savi.state_dict())
+    videos = synth.synth_videos(2, 3, seed=51)
+    ssd = {k: v.clone() for k, v in savi.state_dict().items()}
+    ref = O.savi_decomp(ssd, videos, None, 3)
+    got = savi.to(DEV)(mode="decomp", x=gpu(videos), num_imgs=3, decode=False)["slot_history"]
+    assert max_abs(got.cpu(), ref) < 1e-4

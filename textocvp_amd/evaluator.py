@@ -63,6 +63,9 @@ def gather_metrics(local, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size(group)
+    home = local.device
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.cpu()            # single-GPU rehearsal: gloo moves host copies
     n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
@@ -72,4 +75,4 @@ def gather_metrics(local, group=None):
     padded[:local.shape[0]] = local
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(home)
