@@ -23,7 +23,7 @@ import torch.nn.functional as F
 __all__ = [
     "layer_norm", "linear", "build_grid", "savi_encode", "slot_attention", "transition_block",
     "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
-    "forward_eval", "sub",
+    "forward_eval", "sub", "uncond_step", "encoder_layer_prenorm", "sinusoid_pe",
 ]
 
 
@@ -299,15 +299,75 @@ def text_ocvp_step(sd, window, text, residual=True):
     return out + window[:, -1] if residual else out
 
 
+# ------------------------------------------------------------------------------------------------
+# Unconditioned predictors  (models/Predictors/OCVP.py)
+# ------------------------------------------------------------------------------------------------
+
+def sinusoid_pe(max_len, d_model):
+    """ SlotPositionalEncoding table, models/Blocks/model_blocks.py:258-266 (NOT flipped, :288) """
+    pos = torch.arange(max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def encoder_layer_prenorm(p, x, heads):
+    """ nn.TransformerEncoderLayer(norm_first=True, batch_first=True, relu, eps 1e-5) in eval mode """
+    E = x.shape[-1]
+    h = layer_norm(x, p["norm1.weight"], p["norm1.bias"], 1e-5)
+    qkv = linear(h, p["self_attn.in_proj_weight"], p["self_attn.in_proj_bias"])
+    a = attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, (E // heads) ** -0.5)
+    x = x + linear(a, p["self_attn.out_proj.weight"], p["self_attn.out_proj.bias"])
+    h = layer_norm(x, p["norm2.weight"], p["norm2.bias"], 1e-5)
+    return x + linear(torch.relu(linear(h, p["linear1.weight"], p["linear1.bias"])),
+                      p["linear2.weight"], p["linear2.bias"])
+
+
+def uncond_step(sd, window, kind, heads=4, buffer_size=10, residual=True):
+    """
+    VanillaTransformerPredictor.forward (OCVP.py:100-132) / OCVPSeq.forward (:222-254) with
+    OCVPSeqLayer.forward (:301-320); ``sd`` = weights below 'predictor.'.
+    """
+    B, w, K, D = window.shape
+    tok = linear(window, sd["mlp_in.weight"], sd["mlp_in.bias"])
+    E = tok.shape[-1]
+    tok = tok + sinusoid_pe(buffer_size, E)[:w][None, :, None, :]
+    li = 0
+    if kind == "VanillaTransformer":
+        x = tok.reshape(B, w * K, E)
+        while f"transformer_encoders.{li}.linear1.weight" in sd:
+            x = encoder_layer_prenorm(sub(sd, f"transformer_encoders.{li}."), x, heads)
+            li += 1
+        last = x.reshape(B, w, K, E)[:, -1]
+    elif kind == "OCVPSeq":
+        x = tok
+        while f"transformer_encoders.{li}.object_encoder_block.linear1.weight" in sd:
+            p = sub(sd, f"transformer_encoders.{li}.")
+            x = encoder_layer_prenorm(sub(p, "object_encoder_block."), x.reshape(B * w, K, E), heads)
+            x = x.reshape(B, w, K, E).transpose(1, 2).reshape(B * K, w, E)
+            x = encoder_layer_prenorm(sub(p, "time_encoder_block."), x, heads)
+            x = x.reshape(B, K, w, E).transpose(1, 2)
+            li += 1
+        last = x[:, -1]
+    else:
+        raise ValueError(kind)
+    out = linear(last, sd["mlp_out.weight"], sd["mlp_out.bias"])
+    return out + window[:, -1] if residual else out
+
+
 def rollout(sd, slot_history, tokens, lengths, num_context, num_preds, buffer_size=10,
-            teacher_force=False):
+            teacher_force=False, kind="TextOCVP_CustomTF"):
     """ PredictorWrapper.forward, predictor_wrapper.py:50-87 (sd keys start with 'predictor.'). """
     p = sub(sd, "predictor.")
-    text = text_encoder(sub(p, "text_encoder."), tokens, lengths)
+    text = text_encoder(sub(p, "text_encoder."), tokens, lengths) if kind == "TextOCVP_CustomTF" \
+        else None
     window = slot_history[:, :num_context].clone()
     preds = []
     for t in range(num_preds):
-        cur = text_ocvp_step(p, window, text)
+        cur = text_ocvp_step(p, window, text) if text is not None else \
+            uncond_step(p, window, kind, buffer_size=buffer_size)
         nxt = slot_history[:, num_context + t] if teacher_force else cur
         window = torch.cat([window, nxt.unsqueeze(1)], dim=1)
         if window.shape[1] > buffer_size:                          # :143-153

@@ -228,6 +228,34 @@ def e2e_fixtures(out_dir):
 
 
 @torch.no_grad()
+def uncond_fixtures(out_dir):
+    """ VanillaTransformer / OCVPSeq (models/Predictors/OCVP.py): one step + a 4-step rollout, K=7 """
+    import_reference()
+    from models.Predictors.OCVP import OCVPSeq, VanillaTransformerPredictor
+    from models.Predictors.predictor_wrapper import PredictorWrapper
+    K, D, buf = 7, 128, 10
+    fx, man = {}, {}
+    for name, cls in (("VanillaTransformer", VanillaTransformerPredictor), ("OCVPSeq", OCVPSeq)):
+        cfg = load_cfg(f"predictors/{name}.json")
+        core = cls(num_slots=K, slot_dim=D, input_buffer_size=buf, **cfg["predictor_params"])
+        exp_params = {"predictor": cfg,
+                      "prediction_params": {"num_context": 2, "num_preds": 4, "teacher_force": False,
+                                            "input_buffer_size": buf}}
+        wrapper = PredictorWrapper(exp_params=exp_params, predictor=core).eval()
+        synth.fill_module_(wrapper, seed=0, prefix=f"{name}.")
+        man[name] = {k: list(v.shape) for k, v in wrapper.state_dict().items()}
+        win = synth.synth_tensor("unit.win3", (2, 3, K, D), "normal")
+        fx[f"{name}_step_w3"] = core(slots=win).numpy()
+        hist = synth.synth_tensor("unit.hist6", (2, 6, K, D), "normal")
+        tokens, lengths = synth.synth_captions(2, max_len=8, seed=9)
+        fx[f"{name}_rollout"] = wrapper(hist, caption_tokens=tokens, caption_lengths=lengths).numpy()
+    np.savez(os.path.join(out_dir, "uncond_k7.npz"), **fx)
+    with open(os.path.join(out_dir, "state_dict_manifest_uncond.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("uncond_k7:", {k: v.shape for k, v in fx.items()})
+
+
+@torch.no_grad()
 def manifest(out_dir):
     """ state_dict key/shape manifest = the checkpoint-layout contract. """
     savi, wrapper = build_reference(num_slots=30, num_context=1, num_preds=19)
@@ -242,10 +270,12 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
         unit_fixtures(HERE)
     if "e2e" in what:
         e2e_fixtures(HERE)
+    if "uncond" in what:
+        uncond_fixtures(HERE)

@@ -103,3 +103,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "synth.py", os.path.join(dirpath, f)
+
+
+def test_unconditioned_predictor_layouts():
+    """ VanillaTransformer / OCVPSeq wrappers expose the reference's state_dict keys and shapes """
+    import json
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest_uncond.json")))
+    for name in ("VanillaTransformer", "OCVPSeq"):
+        exp = default_exp_params(num_slots=7, num_context=2, num_preds=4, predictor_name=name)
+        pred = setup_predictor(exp)
+        got = {k: list(v.shape) for k, v in pred.state_dict().items()}
+        assert got == man[name], name
+    with pytest.raises(NotImplementedError):
+        setup_predictor(default_exp_params(predictor_name="TextOCVP_T5"))
+    # the reference wrapper demands caption tokens even for unconditioned predictors
+    pred = setup_predictor(default_exp_params(num_slots=7, predictor_name="OCVPSeq"))
+    with torch.no_grad(), pytest.raises(KeyError):
+        pred(torch.zeros(1, 3, 7, 128))

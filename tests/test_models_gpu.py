@@ -264,3 +264,23 @@ def test_learned_initializer_and_identity_transition():
     ref = O.savi_decomp(ssd, videos, None, 3)
     got = savi.to(DEV)(mode="decomp", x=gpu(videos), num_imgs=3, decode=False)["slot_history"]
     assert max_abs(got.cpu(), ref) < 1e-4
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", ["VanillaTransformer", "OCVPSeq"])
+def test_unconditioned_predictors_against_reference_golden(name):
+    """ the unconditioned OCVP predictors behind the same wrapper """
+    g = load_golden("uncond_k7.npz")
+    K, D = 7, 128
+    exp = default_exp_params(num_slots=K, num_context=2, num_preds=4, predictor_name=name)
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(pred, prefix=f"{name}.")
+    pred = pred.to(DEV)
+    win = synth.synth_tensor("unit.win3", (2, 3, K, D), "normal")
+    hist = synth.synth_tensor("unit.hist6", (2, 6, K, D), "normal")
+    tokens, lengths = synth.synth_captions(2, max_len=8, seed=9)
+    step = pred.predictor(slots=gpu(win))
+    assert max_abs(step.cpu(), g[f"{name}_step_w3"]) < 5e-5
+    roll = pred(gpu(hist), caption_tokens=gpu(tokens), caption_lengths=gpu(lengths))
+    assert roll.shape == (2, 4, K, D)
+    assert max_abs(roll.cpu(), g[f"{name}_rollout"]) < 1e-4

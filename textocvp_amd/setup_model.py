@@ -12,6 +12,7 @@ import torch
 from .models.SAVi import SAVi
 from .models.Predictors.predictor_wrapper import PredictorWrapper
 from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
+from .models.Predictors.OCVP import OCVPSeq, VanillaTransformerPredictor
 
 __all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params"]
 
@@ -38,14 +39,22 @@ _PREDICTOR_DEFAULT = {
 }
 
 
+# configs/predictors/VanillaTransformer.json, OCVPSeq.json
+_UNCOND_DEFAULT = {"token_dim": 128, "hidden_dim": 256, "num_layers": 2, "n_heads": 4, "residual": True}
+
+
 def default_exp_params(num_slots=8, num_context=1, num_preds=9, input_buffer_size=10,
-                       teacher_force=False):
-    """ experiment_params.json-shaped dict with the shipped SAVi / TextOCVP_CustomTF configs """
+                       teacher_force=False, predictor_name="TextOCVP_CustomTF"):
+    """ experiment_params.json-shaped dict with the shipped SAVi / predictor configs """
     model = copy.deepcopy(_SAVI_DEFAULT)
     model["num_slots"] = num_slots
+    if predictor_name == "TextOCVP_CustomTF":
+        predictor = copy.deepcopy(_PREDICTOR_DEFAULT)
+    else:
+        predictor = {"predictor_name": predictor_name, "predictor_params": dict(_UNCOND_DEFAULT)}
     return {
         "model": {"model_name": "SAVi", "model_params": model},
-        "predictor": copy.deepcopy(_PREDICTOR_DEFAULT),
+        "predictor": predictor,
         "prediction_params": {"num_context": num_context, "num_preds": num_preds,
                               "teacher_force": teacher_force,
                               "input_buffer_size": input_buffer_size},
@@ -73,8 +82,12 @@ def setup_predictor(exp_params):
         core = TextOCVP_CustomTF(slot_dim=model_params["slot_dim"], predictor_params=inner,
                                  fusion_params=pp.get("fusion_params"),
                                  text_encoder_params=pp.get("text_encoder_params"))
+    elif name in ("VanillaTransformer", "OCVPSeq"):
+        cls = VanillaTransformerPredictor if name == "VanillaTransformer" else OCVPSeq
+        core = cls(num_slots=model_params["num_slots"], slot_dim=model_params["slot_dim"],
+                   input_buffer_size=exp_params["prediction_params"]["input_buffer_size"], **pp)
     else:
-        raise NotImplementedError(f"predictor {name!r} is not built yet (SURVEY 8f rank 4)")
+        raise NotImplementedError(f"predictor {name!r} is not built (TextOCVP_T5 needs hub weights)")
     return PredictorWrapper(exp_params=exp_params, predictor=core)
 
 
