@@ -229,6 +229,18 @@ int tocvp_text_embed_f32(const int64_t* tokens, const float* tok_emb, const floa
 int tocvp_slot_init_f32(const float* mu, const float* sigma, const float* noise, float* out,
                         int rows, int D, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Evaluation metrics that consume the rendered frames (reference lib/metrics.py:181-255, which
+ * delegates to piqa==1.2.2 -- not vendored; the published definitions are restated):
+ *   psnr[n] = 10 log10(1 / (mse_n + 1e-8)),   ssim[n] = mean SSIM map (11-tap Gaussian sigma 1.5,
+ *   valid padding, k1 0.01, k2 0.03, channel average).  preds/targets: (N, C, H, W) fp32;
+ *   clamp01 != 0 clamps both to [0,1] on load (the evaluator's clamp, 05_evaluate_predictor.py:96-99).
+ *   psnr or ssim may be NULL.  ws: tocvp_metrics_ws_bytes(N, C) bytes.  H*W*8 <= 160 KiB.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_metrics_ws_bytes(int N, int C);
+int tocvp_psnr_ssim_f32(const float* preds, const float* targets, float* psnr, float* ssim, int N,
+                        int C, int H, int W, int clamp01, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

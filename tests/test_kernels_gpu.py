@@ -270,3 +270,36 @@ def test_gemm_split_bf16(mode, tol, M, N, K):
     err32 = (got32.cpu().double() - ref).abs().max().item()
     print(f"{mode} gemm {M}x{N}x{K}: err {err:.2e} (fp32 mfma {err32:.2e}) at scale {scale:.3g}")
     assert err < tol * scale
+
+
+@pytest.mark.parametrize("N,H,W", [(5, 64, 64), (2, 32, 48)])
+def test_psnr_ssim_kernel(N, H, W):
+    """ metric kernel (fused clamp) vs the float64 restatement of piqa's PSNR / SSIM definitions """
+    from oracle import metrics_oracle as MO
+    k = _k()
+    x = rnd("mx", (N, 3, H, W), "unit", 1.3) - 0.1            # exercises the clamp on both sides
+    y = (x + rnd("my", (N, 3, H, W), "normal", 0.05)).clamp(-0.2, 1.2)
+    y[0] = x[0]                                               # identical pair: ssim = 1, psnr = 80 dB
+    p, s = k.psnr_ssim(x.to(DEV), y.to(DEV), clamp01=True)
+    xc, yc = x.clamp(0, 1), y.clamp(0, 1)
+    close(p, MO.psnr(xc, yc), tol=2e-6)
+    close(s, MO.ssim(xc, yc), tol=2e-5)
+    assert abs(s[0].item() - 1.0) < 1e-5 and abs(p[0].item() - 80.0) < 1e-3
+
+
+def test_metric_tracker_surface(tmp_path):
+    from textocvp_amd.metrics import MetricTracker
+    from oracle import metrics_oracle as MO
+    mt = MetricTracker(metrics=["psnr", "ssim"])
+    a, b = rnd("ta", (2, 4, 3, 64, 64), "unit"), rnd("tb", (2, 4, 3, 64, 64), "unit")
+    mt.accumulate(a.to(DEV), b.to(DEV))
+    mt.accumulate(b.to(DEV), a.to(DEV))
+    mt.aggregate()
+    res = mt.get_results()
+    assert res["psnr"]["framewise"].shape == (4,)
+    ref = MO.ssim(a.reshape(8, 3, 64, 64), b.reshape(8, 3, 64, 64)).mean().item()
+    assert abs(res["ssim"]["mean"] - ref) < 1e-5
+    mt.save_results(str(tmp_path), "r")
+    assert (tmp_path / "results" / "r" / "results.json").exists()
+    with pytest.raises(NotImplementedError):
+        MetricTracker(metrics=["lpips"])

@@ -93,6 +93,11 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_metrics_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "tocvp_psnr_ssim_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]),
     "tocvp_slot_init_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -559,3 +564,18 @@ def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None):
     else:
         run()
     return out
+
+
+def psnr_ssim(preds, targets, clamp01=True, want_psnr=True, want_ssim=True):
+    """ preds, targets (N, C, H, W) fp32 on device -> (psnr (N,), ssim (N,)) (None if not wanted) """
+    _dev_f32(preds, "preds"), _dev_f32(targets, "targets")
+    assert preds.shape == targets.shape and preds.dim() == 4
+    preds, targets = preds.contiguous(), targets.contiguous()
+    N, C, H, W = preds.shape
+    ws = torch.empty(max(1, N * C * 2), device=preds.device, dtype=torch.float32)
+    psnr = torch.empty(N, device=preds.device, dtype=torch.float32) if want_psnr else None
+    ssim = torch.empty(N, device=preds.device, dtype=torch.float32) if want_ssim else None
+    _check(lib().tocvp_psnr_ssim_f32(_ptr(preds), _ptr(targets), _ptr(psnr), _ptr(ssim), N, C, H, W,
+                                     int(bool(clamp01)), _ptr(ws), ws.numel() * 4, _stream()),
+           "tocvp_psnr_ssim_f32")
+    return psnr, ssim
