@@ -230,6 +230,26 @@ int tocvp_slot_init_f32(const float* mu, const float* sigma, const float* noise,
                         int rows, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ExtendedDINOSAUR decode side (models/EncodersDecoders/decoders.py:203-365):
+ *  tocvp_conv3x3_f32: Conv2d(Cin->Cout,k3,p1) with per-channel scale/shift epilogue (BatchNorm in
+ *    eval mode folded: scale = gamma/sqrt(var+eps), shift = (bias-mean)*scale+beta; scale may be
+ *    NULL = 1) and optional ReLU, NHWC fp32, fp32 MFMA.  upsample2 != 0: the input is the nearest x2
+ *    upsampling of x ((nimg,H/2,W/2,Cin)), fused into the tile loader (model_blocks.py:23-45).
+ *    wp: (9, Cout, Cin) from tocvp_pack_conv_weights_f32.  Cin % 64 == 0, Cout % 32 == 0, H % 8 == 0.
+ *  tocvp_slot_composite_f32: decoded (B,K,N,F+1) -> recons (B,N,F) = sum_k feats*softmax_K(alpha),
+ *    masks (B,K,N)   (decoders.py:279-283).  K <= 64.
+ *  tocvp_bilinear_resize_f32: F.interpolate(bilinear, align_corners=False) (decoders.py:291-297);
+ *    x: NHWC with channel stride `cstride` (first C channels used), y: NCHW (n,C,OH,OW).
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
+                      float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
+                      void* stream);
+int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B, int K, int N,
+                             int F, void* stream);
+int tocvp_bilinear_resize_f32(const float* x, float* y, int n, int C, int cstride, int SH, int SW,
+                              int OH, int OW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Evaluation metrics that consume the rendered frames (reference lib/metrics.py:181-255, which
  * delegates to piqa==1.2.2 -- not vendored; the published definitions are restated):
  *   psnr[n] = 10 log10(1 / (mse_n + 1e-8)),   ssim[n] = mean SSIM map (11-tap Gaussian sigma 1.5,

@@ -24,6 +24,7 @@ __all__ = [
     "layer_norm", "linear", "build_grid", "savi_encode", "slot_attention", "transition_block",
     "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
     "forward_eval", "sub", "uncond_step", "encoder_layer_prenorm", "sinusoid_pe",
+    "mlp_patch_decoder", "dinosaur_decomp",
 ]
 
 
@@ -217,6 +218,75 @@ def savi_decode(sd, slots, resolution=(64, 64), in_channels=3):
     recons, alpha = y[:, :, :in_channels], y[:, :, in_channels:]
     masks = torch.softmax(alpha, dim=1)                            # softmax over slots (:254)
     return (recons * masks).sum(dim=1), recons, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# ExtendedDINOSAUR, downstream of the ViT backbone  (models/ExtendedDINOSAUR.py, decoders.py:203-365)
+# ------------------------------------------------------------------------------------------------
+
+def mlp_patch_decoder(sd, slots, img_size, patch_size=14, num_layers_cnn=4):
+    """
+    MLPPatchDecoder.forward (decoders.py:264-307) with ``sd`` = weights below 'decoder.':
+    slots (B, K, D) -> recons_imgs (B,3,S,S), recons_feats (B,N,F), masks (B,K,1,g,g).
+    CNN head schedule as decoders.py:325-365: ConvBlock(3x3, BatchNorm eval, ReLU) [+ nearest x2],
+    final Conv3x3 -> RGB, bilinear resize (align_corners=False) to the image size.
+    """
+    B, K, D = slots.shape
+    pos = sd["pos_embed"]                                          # (1, 1, N, D)
+    N = pos.shape[2]
+    g = int(N ** 0.5)
+    x = slots[:, :, None, :] + pos                                 # broadcast + position (:264-266)
+    i = 0
+    if "mlp.0.weight" in sd and sd["mlp.0.weight"].dim() == 1:     # initial LayerNorm
+        x = layer_norm(x, sd["mlp.0.weight"], sd["mlp.0.bias"], 1e-5)
+        i = 1
+    lin = [k for k in sorted({int(k.split(".")[1]) for k in sd if k.startswith("mlp.")}) if k >= i
+           and sd[f"mlp.{k}.weight"].dim() == 2]
+    for j, li in enumerate(lin):
+        x = linear(x, sd[f"mlp.{li}.weight"], sd[f"mlp.{li}.bias"])
+        if j < len(lin) - 1:
+            x = torch.relu(x)
+    feats, alpha = x[..., :-1], x[..., -1:]
+    alpha = torch.softmax(alpha, dim=1)
+    recons_feats = (feats * alpha).sum(dim=1)                      # (B, N, F)
+    masks = alpha.reshape(B, K, 1, g, g)
+
+    y = recons_feats.permute(0, 2, 1).reshape(B, -1, g, g)
+    size, li = g, 0
+    for i in range(num_layers_cnn):
+        p = f"conv_patch_decoder.{li}.block."
+        y = F.conv2d(y, sd[p + "0.weight"], sd[p + "0.bias"], padding=1)
+        y = (y - sd[p + "1.running_mean"][None, :, None, None]) / torch.sqrt(
+            sd[p + "1.running_var"][None, :, None, None] + 1e-5) * sd[p + "1.weight"][None, :, None, None] \
+            + sd[p + "1.bias"][None, :, None, None]
+        y = torch.relu(y)
+        li += 1
+        if (i + 1) * 2 < patch_size and size < img_size:
+            y = F.interpolate(y, scale_factor=2, mode="nearest")
+            size *= 2
+            li += 1
+    y = F.conv2d(y, sd[f"conv_patch_decoder.{li}.weight"], sd[f"conv_patch_decoder.{li}.bias"], padding=1)
+    if y.shape[-1] != img_size:
+        y = F.interpolate(y, size=(img_size, img_size), mode="bilinear", align_corners=False)
+    return y, recons_feats, masks
+
+
+def dinosaur_decomp(sd, feats, noise, iters_first=3, iters=1, trans_heads=4):
+    """
+    ExtendedDINOSAUR.forward_decomp (:139-208) downstream of the backbone: feats (B, T, N, Dm) patch
+    features -> slot_history (B, T, K, D).  linear_feat_proj = LN -> Linear -> ReLU -> Linear (:96-101).
+    """
+    pred = sd["initializer.slots_mu"] + sd["initializer.slots_sigma"] * noise
+    sa, tr = sub(sd, "slot_attention."), sub(sd, "transition_module.")
+    hist = []
+    for t in range(feats.shape[1]):
+        z = layer_norm(feats[:, t], sd["linear_feat_proj.0.weight"], sd["linear_feat_proj.0.bias"], 1e-5)
+        z = torch.relu(linear(z, sd["linear_feat_proj.1.weight"], sd["linear_feat_proj.1.bias"]))
+        z = linear(z, sd["linear_feat_proj.3.weight"], sd["linear_feat_proj.3.bias"])
+        slots = slot_attention(sa, z, pred, iters_first if t == 0 else iters)
+        pred = transition_block(tr, slots, trans_heads)
+        hist.append(slots)
+    return torch.stack(hist, dim=1)
 
 
 # ------------------------------------------------------------------------------------------------

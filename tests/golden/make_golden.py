@@ -256,6 +256,35 @@ def uncond_fixtures(out_dir):
 
 
 @torch.no_grad()
+def dinosaur_fixtures(out_dir):
+    """
+    ExtendedDINOSAUR decode side (BASELINE config 4: 24 slots, 224x224 -> 256 patches): the
+    reference's MLPPatchDecoder incl. the CNN image head (decoders.py:203-365), B = 1.
+    The ViT backbone (timm) is not importable here; everything upstream of the decoder reuses
+    units already pinned (slot attention, transition).
+    """
+    import_reference()
+    from models.EncodersDecoders.decoders import get_decoder
+    cfg = load_cfg("models/ExtendedDINOSAUR.json")
+    dp = copy.deepcopy(cfg["decoder"])
+    dp["decoder_params"]["num_patches"] = 256
+    dp["decoder_params"]["img_size"] = 224
+    dec = get_decoder(in_channels=3, decoder=dp).eval()
+    synth.fill_module_(dec, seed=0, prefix="dino.decoder.")
+    slots = synth.synth_tensor("unit.dino_slots", (1, 24, 128), "normal")
+    out = dec(slots)
+    fx = {"recons_imgs_sub2": out["recons_imgs"][..., ::2, ::2].numpy(),
+          "recons_feats_sub4": out["recons_feats"][:, ::4, ::4].numpy(),
+          "masks": out["masks"].numpy()}
+    np.savez(os.path.join(out_dir, "dinosaur_dec.npz"), **fx)
+    man = {k: list(v.shape) for k, v in dec.state_dict().items()}
+    with open(os.path.join(out_dir, "state_dict_manifest_dinosaur_decoder.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("dinosaur_dec:", {k: v.shape for k, v in fx.items()},
+          {k: (float(v.min()), float(v.max())) for k, v in fx.items()})
+
+
+@torch.no_grad()
 def manifest(out_dir):
     """ state_dict key/shape manifest = the checkpoint-layout contract. """
     savi, wrapper = build_reference(num_slots=30, num_context=1, num_preds=19)
@@ -270,7 +299,7 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -279,3 +308,5 @@ if __name__ == "__main__":
         e2e_fixtures(HERE)
     if "uncond" in what:
         uncond_fixtures(HERE)
+    if "dinosaur" in what:
+        dinosaur_fixtures(HERE)

@@ -120,3 +120,19 @@ def test_unconditioned_predictor_layouts():
     pred = setup_predictor(default_exp_params(num_slots=7, predictor_name="OCVPSeq"))
     with torch.no_grad(), pytest.raises(KeyError):
         pred(torch.zeros(1, 3, 7, 128))
+
+
+def test_dinosaur_layout_and_backbone_guard():
+    import json
+    from textocvp_amd.setup_model import default_dinosaur_params
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest_dinosaur_decoder.json")))
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224))
+    got = {k[len("decoder."):]: list(v.shape) for k, v in model.state_dict().items()
+           if k.startswith("decoder.")}
+    assert got == man
+    assert not any(k.startswith("encoder.") for k in model.state_dict())
+    for k in ("linear_feat_proj.0.weight", "linear_feat_proj.3.bias", "slot_attention.to_q.weight",
+              "initializer.slots_mu", "transition_module.attn.q.weight"):
+        assert k in model.state_dict(), k
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        model(mode="decomp", x=torch.zeros(1, 2, 3, 224, 224), num_imgs=2)    # ViT not vendored

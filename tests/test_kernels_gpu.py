@@ -303,3 +303,34 @@ def test_metric_tracker_surface(tmp_path):
     assert (tmp_path / "results" / "r" / "results.json").exists()
     with pytest.raises(NotImplementedError):
         MetricTracker(metrics=["lpips"])
+
+
+@pytest.mark.parametrize("Cin,Cout,S,up", [(128, 64, 24, False), (64, 128, 16, True), (192, 32, 40, False)])
+def test_conv3x3_scale_shift_upsample(Cin, Cout, S, up):
+    k = _k()
+    x = rnd("c3x", (2, S, S, Cin))
+    w = rnd("c3w", (Cout, Cin, 3, 3), "uniform", (9 * Cin) ** -0.5)
+    sc, sf = 1 + rnd("c3s", (Cout,), "uniform", 0.3), rnd("c3f", (Cout,), "uniform", 0.2)
+    xin = x.permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w, None, padding=1) * sc[None, :, None, None] + sf[None, :, None, None]
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    wp = k.pack_conv_weights(w.to(DEV))
+    got = k.conv3x3(x.to(DEV), wp, sc.to(DEV), sf.to(DEV), relu=True, upsample2=up)
+    close(got, ref)
+
+
+def test_slot_composite_and_bilinear():
+    k = _k()
+    dec = rnd("scd", (2, 24, 50, 97))
+    feats, alpha = dec[..., :-1], dec[..., -1:]
+    a = torch.softmax(alpha, dim=1)
+    rec, masks = k.slot_composite(dec.to(DEV))
+    close(rec, (feats * a).sum(1))
+    close(masks, a[..., 0], tol=1e-6)
+    x = rnd("bil", (2, 48, 48, 32))
+    ref = F.interpolate(x[..., :3].permute(0, 3, 1, 2), size=(42, 42), mode="bilinear", align_corners=False)
+    close(k.bilinear_resize_nhwc_to_nchw(x.to(DEV), 3, 42, 42), ref, tol=2e-6)
+    ref_up = F.interpolate(x[..., :3].permute(0, 3, 1, 2), size=(60, 60), mode="bilinear", align_corners=False)
+    close(k.bilinear_resize_nhwc_to_nchw(x.to(DEV), 3, 60, 60), ref_up, tol=2e-6)

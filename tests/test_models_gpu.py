@@ -284,3 +284,34 @@ def test_unconditioned_predictors_against_reference_golden(name):
     roll = pred(gpu(hist), caption_tokens=gpu(tokens), caption_lengths=gpu(lengths))
     assert roll.shape == (2, 4, K, D)
     assert max_abs(roll.cpu(), g[f"{name}_rollout"]) < 1e-4
+
+
+@torch.no_grad()
+def test_dinosaur_decode_side_config4():
+    """
+    BASELINE config 4 downstream of the ViT: 24 slots, 224x224 (256 patches), decoder incl. CNN
+    image head against the reference golden; recurrence from patch features against the oracle.
+    """
+    from textocvp_amd.setup_model import default_dinosaur_params
+    g = load_golden("dinosaur_dec.npz")
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224)).eval()
+    synth.fill_module_(model, prefix="dino.")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    slots = synth.synth_tensor("unit.dino_slots", (1, 24, 128), "normal")
+    out = model(mode="decode", slots=gpu(slots))
+    assert out["recons_imgs"].shape == (1, 3, 224, 224) and out["masks"].shape == (1, 24, 1, 16, 16)
+    assert max_abs(out["recons_feats"][:, ::4, ::4].cpu(), g["recons_feats_sub4"]) < 1e-4
+    assert max_abs(out["masks"].cpu(), g["masks"]) < 1e-5
+    assert max_abs(out["recons_imgs"][..., ::2, ::2].cpu(), g["recons_imgs_sub2"]) < 2e-6
+
+    feats = synth.synth_tensor("unit.dino_feats", (2, 3, 256, 768), "normal")
+    noise = synth.synth_noise(2, 24, 128, seed=61)
+    ref = O.dinosaur_decomp(sd, feats, noise)
+    got = model(mode="decomp", num_imgs=3, decode=True, encoded_img_feats=gpu(feats), init_noise=noise)
+    assert max_abs(got["slot_history"].cpu(), ref) < 1e-4
+    assert got["recons_imgs"].shape == (2, 3, 3, 224, 224)
+    assert got["recons_feats"].shape == (2, 3, 256, 768) and got["masks"].shape == (2, 3, 24, 1, 16, 16)
+    ref_imgs, ref_feats, _ = O.mlp_patch_decoder(O.sub(sd, "decoder."), ref[0], img_size=224)
+    assert max_abs(got["recons_feats"][0].cpu(), ref_feats) < 2e-4
+    assert max_abs(got["recons_imgs"][0].cpu(), ref_imgs) < 5e-6

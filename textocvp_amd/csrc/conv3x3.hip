@@ -1,0 +1,245 @@
+// Kernels of the ExtendedDINOSAUR decode side (reference models/EncodersDecoders/decoders.py:203-365):
+//
+//  conv3x3_mfma_kernel   : Conv2d(Cin->Cout, k3, p1) + folded BatchNorm(eval) + ReLU as an implicit
+//                          GEMM on fp32 MFMA, NHWC; optional nearest x2 upsampling of the INPUT fused
+//                          into the tile loader (model_blocks.py:23-45 `Upsample` between blocks of the
+//                          CNN image head never materialises the 4x larger tensor).
+//                          Cin % 64 == 0, Cout % 32 == 0, any H % 8 == 0, any W (masked stores).
+//                          Same geometry as conv5x5_mfma_kernel: 8 x 32 pixel tile x 64 (or 32) output
+//                          channels per workgroup, halo tile (10 x 34 x 64ch) staged per 64-channel
+//                          chunk, per-tap weight slices double-buffered in LDS.
+//  slot_composite_kernel : alpha-softmax over slots + weighted feature sum of MLPPatchDecoder.forward
+//                          (decoders.py:279-283).
+//  bilinear_resize_kernel: F.interpolate(mode='bilinear', align_corners=False) of the image head
+//                          (decoders.py:291-297), NHWC in -> NCHW out.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;
+constexpr int CC = 64, CS = CC + 4;
+
+struct Conv3Args {
+    const float* x; const float* wp; const float* scale; const float* shift; float* y;
+    int nimg, H, W, Cin, Cout, relu, upsample;   // H, W = OUTPUT (= conv input after upsampling) size
+};
+
+template <int NB>   // 32-channel output blocks per workgroup (2 -> 64 channels, 1 -> 32)
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Args p) {
+    constexpr int COUTB = NB * 32;
+    constexpr int F4 = CC / 4;
+    constexpr int WREG = (COUTB * F4) / 256;
+    constexpr int NIT = (IH * IW * F4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[IH * IW * CS + 2 * COUTB * CS];
+    float* in_s = lds;
+    float* w_s = lds + IH * IW * CS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles = tiles_x * (p.H / TH);
+    const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    const int co0 = blockIdx.y * COUTB;
+    const int SH = p.upsample ? p.H / 2 : p.H, SW = p.upsample ? p.W / 2 : p.W;   // source size
+    const int sh = p.upsample ? 1 : 0;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 wreg[WREG];
+    auto wload = [&](int tap, int ch) {
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = t + 256 * i;
+            const int co = idx / F4, c = (idx % F4) * 4;
+            wreg[i] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)tap * p.Cout + co0 + co) * p.Cin +
+                                                      ch * CC + c);
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = t + 256 * i;
+            const int co = idx / F4, c = (idx % F4) * 4;
+            *reinterpret_cast<f32x4*>(w_s + buf * COUTB * CS + co * CS + c) = wreg[i];
+        }
+    };
+
+    const int nch = p.Cin / CC;
+    for (int ch = 0; ch < nch; ++ch) {
+        // halo tile of this channel chunk: batched loads from clamped addresses, zeroed outside
+        f32x4 tv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(t + it * 256, IH * IW * F4 - 1);
+            const int pix = i / F4, c = (i % F4) * 4;
+            const int iy = min(max(ty0 + pix / IW - 1, 0), p.H - 1) >> sh;
+            const int ix = min(max(tx0 + pix % IW - 1, 0), p.W - 1) >> sh;
+            tv[it] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * SH + iy) * SW + ix) * p.Cin +
+                                                     ch * CC + c);
+        }
+        wload(0, ch);
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = t + it * 256;
+            if (i < IH * IW * F4) {
+                const int pix = i / F4, c = (i % F4) * 4;
+                const int iy = ty0 + pix / IW - 1, ix = tx0 + pix % IW - 1;
+                const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                f32x4 v = tv[it];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
+                *reinterpret_cast<f32x4*>(in_s + pix * CS + c) = v;
+            }
+        }
+        wstore(0);
+        __syncthreads();
+
+        for (int tap = 0; tap < 9; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 9) wload(tap + 1, ch);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tap / 3, dx = tap % 3;
+            const float* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * CS + 4 * h;
+            const float* b_base = w_s + buf * COUTB * CS + l31 * CS + 4 * h;
+#pragma unroll
+            for (int j = 0; j < CC / 8; ++j) {
+                f32x4 a[2], b[NB];
+                a[0] = *reinterpret_cast<const f32x4*>(a_base + 8 * j);
+                a[1] = *reinterpret_cast<const f32x4*>(a_base + IW * CS + 8 * j);
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    b[n] = *reinterpret_cast<const f32x4*>(b_base + n * 32 * CS + 8 * j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) acc[m][n] = mfma32(a[m][u], b[n][u], acc[m][n]);
+            }
+            if (tap + 1 < 9) wstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int co = co0 + n * 32 + l31;
+        const float sc = p.scale ? p.scale[co] : 1.f, sf = p.shift[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = ty0 + 2 * wave + m;
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W) * p.Cout + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = tx0 + acc_row(r, h);
+                if (ox < p.W) {
+                    float v = fmaf(acc[m][n][r], sc, sf);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    yrow[(size_t)ox * p.Cout] = v;
+                }
+            }
+        }
+    }
+}
+
+// decoded (B, K, N, F+1) -> recons (B, N, F), masks (B, K, N):  alpha = softmax_K(decoded[..., F])
+__global__ __launch_bounds__(256) void slot_composite_kernel(const float* __restrict__ dec,
+                                                             float* __restrict__ recons,
+                                                             float* __restrict__ masks, int K, int N,
+                                                             int F) {
+    __shared__ float a_s[64];
+    const int b = blockIdx.y, n = blockIdx.x, t = threadIdx.x;
+    const size_t row = (size_t)F + 1;
+    const float* base = dec + ((size_t)b * K * N + n) * row;          // slot k at + k*N*row
+    if (t < 64) {
+        float a = (t < K) ? base[(size_t)t * N * row + F] : -1.0e30f;
+        float m = a;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float e = (t < K) ? expf(a - m) : 0.f;
+        const float s = wave_sum64(e);
+        const float w = e / s;
+        a_s[t] = w;
+        if (t < K) masks[((size_t)b * K + t) * N + n] = w;
+    }
+    __syncthreads();
+    for (int f = t; f < F; f += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += base[(size_t)k * N * row + f] * a_s[k];
+        recons[((size_t)b * N + n) * F + f] = acc;
+    }
+}
+
+// NHWC (n, SH, SW, C) -> NCHW (n, C, OH, OW), bilinear, align_corners=False (PyTorch semantics)
+__global__ __launch_bounds__(256) void bilinear_resize_kernel(const float* __restrict__ x,
+                                                              float* __restrict__ y, int C, int CSTR,
+                                                              int SH, int SW, int OH, int OW,
+                                                              long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const int c = (int)((i / ((long)OW * OH)) % C);
+    const long n = i / ((long)OW * OH * C);
+    const float ry = (float)SH / (float)OH, rx = (float)SW / (float)OW;
+    float fy = ((float)oy + 0.5f) * ry - 0.5f, fx = ((float)ox + 0.5f) * rx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < SH - 1 ? 1 : 0), x1 = x0 + (x0 < SW - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* xp = x + (size_t)n * SH * SW * CSTR + c;
+    const float v00 = xp[((size_t)y0 * SW + x0) * CSTR], v01 = xp[((size_t)y0 * SW + x1) * CSTR];
+    const float v10 = xp[((size_t)y1 * SW + x0) * CSTR], v11 = xp[((size_t)y1 * SW + x1) * CSTR];
+    y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+}  // namespace
+
+extern "C" int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale,
+                                 const float* shift, float* y, int nimg, int H, int W, int Cin,
+                                 int Cout, int relu, int upsample2, void* stream) {
+    TOCVP_CHECK_ARG(x && wp && shift && y);
+    TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0);
+    TOCVP_CHECK_ARG(Cin > 0 && (Cin % CC) == 0 && Cout > 0 && (Cout % 32) == 0);
+    TOCVP_CHECK_ARG(!upsample2 || ((H % 2) == 0 && (W % 2) == 0));
+    const size_t tiles = (size_t)((W + TW - 1) / TW) * (H / TH);
+    TOCVP_CHECK_ARG(nimg * tiles < 0x7fffffffu && Cout / 32 <= 65535);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(wp)) return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    Conv3Args a{x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2 ? 1 : 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout % 64 == 0)
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3((unsigned)(nimg * tiles), Cout / 64), dim3(256),
+                           0, s, a);
+    else
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3((unsigned)(nimg * tiles), Cout / 32), dim3(256),
+                           0, s, a);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B,
+                                        int K, int N, int F, void* stream) {
+    TOCVP_CHECK_ARG(decoded && recons && masks);
+    TOCVP_CHECK_ARG(B >= 0 && B <= 65535 && K > 0 && K <= 64 && N > 0 && F > 0);
+    if (B == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(slot_composite_kernel, dim3(N, B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), decoded, recons, masks, K, N, F);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_bilinear_resize_f32(const float* x, float* y, int n, int C, int cstride, int SH,
+                                         int SW, int OH, int OW, void* stream) {
+    TOCVP_CHECK_ARG(x && y && n >= 0 && C > 0 && cstride >= C && SH > 0 && SW > 0 && OH > 0 && OW > 0);
+    const long total = (long)n * C * OH * OW;
+    if (total == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(bilinear_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, y, C, cstride, SH, SW, OH, OW, total);
+    return tocvp_launch_status();
+}

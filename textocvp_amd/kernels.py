@@ -98,6 +98,16 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
         ctypes.c_void_p]),
+    "tocvp_conv3x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_slot_composite_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_bilinear_resize_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_slot_init_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -579,3 +589,41 @@ def psnr_ssim(preds, targets, clamp01=True, want_psnr=True, want_ssim=True):
                                      int(bool(clamp01)), _ptr(ws), ws.numel() * 4, _stream()),
            "tocvp_psnr_ssim_f32")
     return psnr, ssim
+
+
+def conv3x3(x, wp, scale, shift, relu=True, upsample2=False):
+    """
+    NHWC (n, SH, SW, Cin) -> (n, H, W, Cout): 3x3 conv (pad 1) + per-channel scale/shift (+ReLU) on
+    the (optionally nearest-x2-upsampled) input; wp packed (9, Cout, Cin).
+    """
+    n, SH, SW, Cin = x.shape
+    H, W = (2 * SH, 2 * SW) if upsample2 else (SH, SW)
+    Cout = wp.shape[1]
+    assert x.is_contiguous() and wp.shape[0] == 9 and wp.shape[2] == Cin
+    y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
+    _check(lib().tocvp_conv3x3_f32(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin,
+                                   Cout, int(bool(relu)), int(bool(upsample2)), _stream()),
+           "tocvp_conv3x3_f32")
+    return y
+
+
+def slot_composite(decoded):
+    """ decoded (B, K, N, F+1) -> recons (B, N, F), masks (B, K, N) """
+    B, Ks, N, F1 = decoded.shape
+    _dev_f32(decoded, "decoded")
+    decoded = decoded.contiguous()
+    recons = torch.empty((B, N, F1 - 1), device=decoded.device, dtype=torch.float32)
+    masks = torch.empty((B, Ks, N), device=decoded.device, dtype=torch.float32)
+    _check(lib().tocvp_slot_composite_f32(_ptr(decoded), _ptr(recons), _ptr(masks), B, Ks, N, F1 - 1,
+                                          _stream()), "tocvp_slot_composite_f32")
+    return recons, masks
+
+
+def bilinear_resize_nhwc_to_nchw(x, channels, out_h, out_w):
+    """ x (n, SH, SW, Cs) NHWC, first ``channels`` channels -> (n, channels, out_h, out_w) """
+    n, SH, SW, Cs = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((n, channels, out_h, out_w), device=x.device, dtype=torch.float32)
+    _check(lib().tocvp_bilinear_resize_f32(_ptr(x), _ptr(y), n, channels, Cs, SH, SW, out_h, out_w,
+                                           _stream()), "tocvp_bilinear_resize_f32")
+    return y

@@ -9,7 +9,23 @@ import torch.nn as nn
 from ... import kernels as K
 from .model_utils import Derived
 
-__all__ = ["ConvBlock", "SoftPositionEmbed", "TemporalPositionalEncoding"]
+__all__ = ["ConvBlock", "Upsample", "SoftPositionEmbed", "TemporalPositionalEncoding"]
+
+
+class Upsample(nn.Module):
+    """
+    Nearest-neighbour upsampling marker (model_blocks.py:23-45).  It owns no parameters; on the
+    MI355X path it is fused into the tile loader of the following convolution.
+    """
+
+    def __init__(self, scale_factor):
+        super().__init__()
+        if scale_factor != 2:
+            raise NotImplementedError("only x2 nearest upsampling is fused into the conv kernel")
+        self.scale_factor = scale_factor
+
+    def __repr__(self):
+        return f"Upsample(scale_factor={self.scale_factor})"
 
 
 class ConvBlock(nn.Module):
@@ -22,19 +38,35 @@ class ConvBlock(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=None,
                  batch_norm=False, max_pool=None, activation=True):
         super().__init__()
-        if batch_norm or max_pool or stride != 1:
-            raise NotImplementedError("ConvBlock: batch_norm / max_pool / stride are not used by "
-                                      "the SAVi configs of the slot-rollout path")
+        if max_pool or stride != 1:
+            raise NotImplementedError("ConvBlock: max_pool / stride are not used on the rollout path")
         padding = padding if padding is not None else kernel_size // 2
         layers = [nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)]
+        if batch_norm:
+            layers.append(nn.BatchNorm2d(num_features=out_channels))
         if activation:
             layers.append(nn.ReLU())
         self.activation = activation
+        self.batch_norm = bool(batch_norm)
         self.block = nn.Sequential(*layers)
 
     @property
     def conv(self):
         return self.block[0]
+
+    def folded_scale_shift(self):
+        """
+        Per-channel (scale, shift) such that block(x) = act(conv_nobias(x) * scale + shift):
+        eval-mode BatchNorm and the conv bias folded together (BatchNorm only exists in the
+        DINOSAUR image head and is affine in eval mode).
+        """
+        conv = self.conv
+        if not self.batch_norm:
+            return None, conv.bias.detach()
+        bn = self.block[1]
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        shift = (conv.bias.detach() - bn.running_mean) * scale + bn.bias.detach()
+        return scale.contiguous(), shift.contiguous()
 
 
 class SoftPositionEmbed(nn.Module):

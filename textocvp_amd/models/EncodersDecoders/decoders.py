@@ -12,7 +12,7 @@ from ... import kernels as K
 from ..Blocks.model_blocks import ConvBlock
 from ..Blocks.model_utils import Derived
 
-__all__ = ["get_decoder", "ConvDecoder"]
+__all__ = ["get_decoder", "ConvDecoder", "MLPPatchDecoder"]
 
 
 def get_decoder(in_channels, decoder, **kwargs):
@@ -22,8 +22,9 @@ def get_decoder(in_channels, decoder, **kwargs):
         return ConvDecoder(in_channels=in_channels, hidden_dims=params.pop("num_channels"),
                            kernel_size=params.pop("kernel_size"), upsample=params.pop("upsample"),
                            out_channels=kwargs.get("out_channels", 4), **params)
-    raise NotImplementedError(
-        f"decoder {name!r}: only 'ConvDecoder' is built so far (MLPPatchDecoder is SURVEY 8f rank 3)")
+    if name == "MLPPatchDecoder":
+        return MLPPatchDecoder(**params)
+    raise NotImplementedError(f"Unknown decoder {name}...")
 
 
 class ConvDecoder(nn.Module):
@@ -133,3 +134,118 @@ class ConvDecoder(nn.Module):
         raise NotImplementedError(
             "ConvDecoder.forward on a materialised (B*K, D, H, W) broadcast is deliberately not "
             "provided: use SAVi.decode / decode_slots (the broadcast tensor never exists here)")
+
+
+class MLPPatchDecoder(nn.Module):
+    """
+    Slot -> ViT-patch-feature decoder of ExtendedDINOSAUR (reference decoders.py:129-365):
+    broadcast slots over the patches + learned position embedding -> [LayerNorm] -> MLP ->
+    (features, alpha) -> softmax over slots -> weighted sum; optional CNN head that renders the
+    image from the reconstructed feature grid (Conv3x3 + BatchNorm + ReLU blocks with nearest x2
+    upsampling in between, final Conv3x3 -> RGB, bilinear resize to the image size).
+
+    MI355X path: the position add is fused into the LayerNorm prologue, the MLP runs on the MFMA
+    GEMMs with fused ReLU, the alpha-softmax + weighted sum is one kernel, eval-mode BatchNorm is
+    folded into the conv epilogue and every nearest upsampling is fused into the NEXT conv's tile
+    loader (the 4x larger tensors are never written).
+    """
+
+    def __init__(self, num_patches, in_dim, hidden_dim, out_dim, num_layers=4,
+                 initial_layer_norm=False, reconstruct_images=False, **kwargs):
+        super().__init__()
+        self.num_patches, self.in_dim = num_patches, in_dim
+        self.pos_embed = nn.Parameter(torch.randn(1, 1, num_patches, in_dim) / (in_dim ** 0.5))
+        self.patch_grid = (int(num_patches ** 0.5), int(num_patches ** 0.5))
+        self.hidden_dim, self.out_dim, self.num_layers = hidden_dim, out_dim, num_layers
+        self.initial_layer_norm = initial_layer_norm
+        mlp = [nn.LayerNorm(in_dim)] if initial_layer_norm else []
+        for i in range(num_layers):
+            d1 = hidden_dim if i > 0 else in_dim
+            d2 = hidden_dim if i < num_layers - 1 else out_dim
+            mlp.append(nn.Linear(d1, d2))
+            if i < num_layers - 1:
+                mlp.append(nn.ReLU())
+        self.mlp = nn.Sequential(*mlp)
+        self.reconstruct_images = reconstruct_images
+        if reconstruct_images:
+            self.patch_size = kwargs.get("patch_size")
+            self.image_size = kwargs.get("img_size")
+            self.num_layers_cnn = kwargs.get("num_layers_cnn")
+            self.conv_patch_decoder, self._upsample_after = self._build_conv_patch_decoder(
+                in_dim=out_dim - 1, hidden_dim=hidden_dim, num_layers=self.num_layers_cnn,
+                patch_size=self.patch_size)
+        self._derived = Derived()
+
+    def _build_conv_patch_decoder(self, in_dim, hidden_dim, num_layers, patch_size):
+        """ same layer / channel / upsampling schedule as the reference (decoders.py:325-365) """
+        from ..Blocks.model_blocks import Upsample
+        mods, ups = [], []
+        size = self.patch_grid[0]
+        for i in range(num_layers):
+            cin = in_dim if i == 0 else hidden_dim
+            if i > 0 and (i + 1) * 2 < patch_size and size < self.image_size:
+                hidden_dim = hidden_dim // 2
+            mods.append(ConvBlock(cin, hidden_dim, kernel_size=3, stride=1, padding=1, batch_norm=True))
+            if (i + 1) * 2 < patch_size and size < self.image_size:
+                mods.append(Upsample(scale_factor=2))
+                size *= 2
+                ups.append(True)
+            else:
+                ups.append(False)
+        mods.append(nn.Conv2d(hidden_dim, 3, kernel_size=3, stride=1, padding=1))
+        return nn.Sequential(*mods), ups
+
+    # -- image head on the kernels ---------------------------------------------------------------
+    def _render(self, feats):
+        """ feats (B, N, F) -> images (B, 3, S, S) """
+        B = feats.shape[0]
+        g = self.patch_grid[0]
+        x = feats.reshape(B, g, g, feats.shape[-1]).contiguous()           # NHWC feature grid
+        blocks = [m for m in self.conv_patch_decoder if isinstance(m, ConvBlock)]
+        up_next = False
+        for blk, up in zip(blocks, self._upsample_after):
+            conv = blk.conv
+            wp = self._derived.get(("wp", id(blk)), [conv.weight],
+                                   lambda c=conv: K.pack_conv_weights(c.weight))
+            sc, sf = self._derived.get(
+                ("ss", id(blk)), [conv.bias] + [t for t in blk.block[1].state_dict().values()
+                                                if t.is_floating_point()],
+                lambda b=blk: b.folded_scale_shift())
+            x = K.conv3x3(x, wp, sc, sf, relu=True, upsample2=up_next)
+            up_next = up
+        final = self.conv_patch_decoder[-1]
+
+        def pack_final():
+            w = torch.zeros((32,) + tuple(final.weight.shape[1:]), device=final.weight.device)
+            w[:3] = final.weight
+            b = torch.zeros(32, device=final.weight.device)
+            b[:3] = final.bias
+            return K.pack_conv_weights(w), b
+        wp, bias = self._derived.get("final", [final.weight, final.bias], pack_final)
+        x = K.conv3x3(x, wp, None, bias, relu=False, upsample2=up_next)    # (B, S', S', 32), 3 used
+        S = self.image_size
+        return K.bilinear_resize_nhwc_to_nchw(x, 3, S, S)                  # also the NHWC->NCHW step
+
+    def forward(self, slots):
+        """ slots (B, K, D) -> {'recons_imgs', 'recons_feats' (B,N,F), 'masks' (B,K,1,g,g)} """
+        B, Ks, D = slots.shape
+        N = self.num_patches
+        x = slots.reshape(B * Ks, 1, D).expand(B * Ks, N, D).contiguous()  # broadcast (data movement)
+        pos = self.pos_embed.detach().reshape(N, D)
+        i = 0
+        if self.initial_layer_norm:
+            ln = self.mlp[0]
+            x = K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=pos)
+            i = 1
+        else:
+            raise NotImplementedError("MLPPatchDecoder without initial_layer_norm (unused by the configs)")
+        linears = [m for m in self.mlp[i:] if isinstance(m, nn.Linear)]
+        for j, lin in enumerate(linears):
+            x = K.linear(x, lin.weight, lin.bias,
+                         act=K.ACT_RELU if j < len(linears) - 1 else K.ACT_NONE)
+        recons_feats, masks = K.slot_composite(x.reshape(B, Ks, N, self.out_dim))
+        recons_imgs = torch.tensor([])
+        if self.reconstruct_images:
+            recons_imgs = self._render(recons_feats)
+        return {"recons_imgs": recons_imgs, "recons_feats": recons_feats,
+                "masks": masks.reshape(B, Ks, 1, *self.patch_grid)}

@@ -10,11 +10,13 @@ import os
 import torch
 
 from .models.SAVi import SAVi
+from .models.ExtendedDINOSAUR import ExtendedDINOSAUR
 from .models.Predictors.predictor_wrapper import PredictorWrapper
 from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
 from .models.Predictors.OCVP import OCVPSeq, VanillaTransformerPredictor
 
-__all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params"]
+__all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params",
+           "default_dinosaur_params"]
 
 # configs/models/SAVi.json + configs/predictors/TextOCVP_CustomTF.json + CONFIG.py:66-71 defaults
 _SAVI_DEFAULT = {
@@ -28,6 +30,26 @@ _SAVI_DEFAULT = {
         "num_channels": [64, 64, 64, 64], "kernel_size": 5, "resolution": [64, 64],
         "downsample_decoder": False, "upsample": 1}},
 }
+# configs/models/ExtendedDINOSAUR.json
+_DINOSAUR_DEFAULT = {
+    "img_size": 336, "in_channels": 3, "num_slots": 10, "slot_dim": 128, "num_iterations_first": 3,
+    "num_iterations": 1, "mlp_hidden": 512, "mlp_encoder_dim": 768, "initializer": "LearnedRandom",
+    "transition_module": {"model_name": "TransformerBlock", "num_heads": 4, "mlp_size": 512},
+    "encoder": {"encoder_name": "vit_base_patch14_dinov2", "encoder_params": {"encoder_num_blocks": 12}},
+    "decoder": {"decoder_name": "MLPPatchDecoder", "decoder_params": {
+        "patch_size": 14, "num_patches": 576, "in_dim": 128, "hidden_dim": 1024, "out_dim": 769,
+        "num_layers": 4, "initial_layer_norm": True, "reconstruct_images": True, "num_layers_cnn": 4}},
+}
+
+
+def default_dinosaur_params(num_slots=10, img_size=336):
+    """ ``exp_params["model"]`` for ExtendedDINOSAUR (num_patches follows img_size / 14) """
+    p = copy.deepcopy(_DINOSAUR_DEFAULT)
+    p["num_slots"], p["img_size"] = num_slots, img_size
+    p["decoder"]["decoder_params"]["num_patches"] = (img_size // 14) ** 2
+    return {"model_name": "ExtendedDINOSAUR", "model_params": p}
+
+
 _PREDICTOR_DEFAULT = {
     "predictor_name": "TextOCVP_CustomTF",
     "predictor_params": {
@@ -68,7 +90,9 @@ def setup_model(model_params):
     params = copy.deepcopy(model_params["model_params"])
     if name == "SAVi":
         return SAVi(**params)
-    raise NotImplementedError(f"'{name = }' is not built yet (supported: ['SAVi'])")
+    if name == "ExtendedDINOSAUR":
+        return ExtendedDINOSAUR(**params)
+    raise NotImplementedError(f"'{name = }' not in supported models: ['SAVi', 'ExtendedDINOSAUR']")
 
 
 def setup_predictor(exp_params):
@@ -106,6 +130,9 @@ def load_checkpoint(checkpoint_path, model, only_model=True, map_cpu=False, **kw
     first_ckpt = next(iter(sd.keys()))
     if first_model.startswith("predictor") and not first_ckpt.startswith("predictor"):
         sd = {f"predictor.{k}": v for k, v in sd.items()}
+    if isinstance(model, ExtendedDINOSAUR):
+        # the frozen timm ViT backbone is not vendored here: its weights are skipped
+        sd = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
     model.load_state_dict(sd)
     if not only_model:
         raise NotImplementedError("optimizer / scheduler state is a training feature (not built)")
