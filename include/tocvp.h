@@ -230,6 +230,22 @@ int tocvp_slot_init_f32(const float* mu, const float* sigma, const float* noise,
                         int rows, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * T5 text encoder pieces of TextOCVP_T5 (models/Predictors/text_cond_OCVP.py:141-151 ->
+ * transformers.T5EncoderModel, un-pinned third-party dependency; its published algorithm restated):
+ *  tocvp_rmsnorm_f32:   T5LayerNorm  y = x * rsqrt(mean(x^2) + eps) * gamma
+ *  tocvp_embedding_f32: token embedding lookup out[r] = table[ids[r]]
+ *  tocvp_mha_bias_f32:  tocvp_mha_f32 with an additive score bias (H, Tq, Tk) shared by the batch
+ *                       (T5's bucketed relative-position bias; T5 uses scale = 1)
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_rmsnorm_f32(const float* x, const float* gamma, float* y, int rows, int D, float eps,
+                      void* stream);
+int tocvp_embedding_f32(const int64_t* ids, const float* table, float* out, int rows, int D,
+                        int vocab, void* stream);
+int tocvp_mha_bias_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                       float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
+                       const int32_t* key_len, const float* bias, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ExtendedDINOSAUR decode side (models/EncodersDecoders/decoders.py:203-365):
  *  tocvp_conv3x3_f32: Conv2d(Cin->Cout,k3,p1) with per-channel scale/shift epilogue (BatchNorm in
  *    eval mode folded: scale = gamma/sqrt(var+eps), shift = (bias-mean)*scale+beta; scale may be

@@ -24,7 +24,7 @@ __all__ = [
     "layer_norm", "linear", "build_grid", "savi_encode", "slot_attention", "transition_block",
     "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
     "forward_eval", "sub", "uncond_step", "encoder_layer_prenorm", "sinusoid_pe",
-    "mlp_patch_decoder", "dinosaur_decomp",
+    "mlp_patch_decoder", "dinosaur_decomp", "t5_encoder",
 ]
 
 
@@ -319,6 +319,56 @@ def text_encoder(sd, tokens, lengths, heads=4):
         li += 1
     x = layer_norm(x, sd["text_out_projection.0.weight"], sd["text_out_projection.0.bias"], 1e-5)
     return linear(x, sd["text_out_projection.1.weight"], sd["text_out_projection.1.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# T5-small encoder of TextOCVP_T5  (text_cond_OCVP.py:141-151 -> transformers.T5EncoderModel)
+# ------------------------------------------------------------------------------------------------
+
+def t5_encoder(sd, ids, mask, heads=8, num_buckets=32, max_distance=128, eps=1e-6):
+    """
+    Restatement of the published T5 encoder (un-pinned third-party dependency `transformers`,
+    environment.yml:22; call site predictor_wrapper.py:101-111): shared embedding, per block
+    RMS-norm -> bias-free q/k/v (NO 1/sqrt(d) scaling) + bucketed relative position bias (block 0's
+    table, shared by all blocks) + key padding mask -> o-proj residual; RMS-norm -> ReLU FFN
+    residual; final RMS-norm.  ``sd`` = weights below 'text_encoder.'.
+    """
+    def rms(x, w):
+        return x * torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + eps) * w
+    B, L = ids.shape
+    h = sd["encoder.embed_tokens.weight"][ids]
+    pos = torch.arange(L)
+    rel = pos[None, :] - pos[:, None]
+    nb = num_buckets // 2
+    bucket = (rel > 0).long() * nb
+    a = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(a.float().clamp(min=1) / max_exact)
+                         / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, nb - 1))
+    bucket = bucket + torch.where(a < max_exact, a, large)
+    bias = sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"][bucket]
+    bias = bias.permute(2, 0, 1)[None]                              # (1, H, L, L)
+    neg = (1.0 - mask[:, None, None, :].to(h.dtype)) * torch.finfo(h.dtype).min
+    li = 0
+    while f"encoder.block.{li}.layer.0.SelfAttention.q.weight" in sd:
+        p = f"encoder.block.{li}.layer."
+        n = rms(h, sd[p + "0.layer_norm.weight"])
+        E = n.shape[-1]
+        dh = E // heads
+        def split(t):
+            return t.reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+        q = split(linear(n, sd[p + "0.SelfAttention.q.weight"]))
+        k = split(linear(n, sd[p + "0.SelfAttention.k.weight"]))
+        v = split(linear(n, sd[p + "0.SelfAttention.v.weight"]))
+        w = torch.softmax(q @ k.transpose(-1, -2) + bias + neg, dim=-1)
+        ctx = (w @ v).permute(0, 2, 1, 3).reshape(B, L, E)
+        h = h + linear(ctx, sd[p + "0.SelfAttention.o.weight"])
+        n = rms(h, sd[p + "1.layer_norm.weight"])
+        h = h + linear(torch.relu(linear(n, sd[p + "1.DenseReluDense.wi.weight"])),
+                       sd[p + "1.DenseReluDense.wo.weight"])
+        li += 1
+    return rms(h, sd["encoder.final_layer_norm.weight"])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -285,6 +285,35 @@ def dinosaur_fixtures(out_dir):
 
 
 @torch.no_grad()
+def t5_fixtures(out_dir):
+    """
+    T5-small encoder as called by the reference for TextOCVP_T5 (predictor_wrapper.py:101-111):
+    transformers.T5EncoderModel(input_ids, attention_mask).last_hidden_state.  The reference loads
+    hub weights (network); the architecture is instantiated from its published t5-small config and
+    filled with synthetic weights, which pins the ARITHMETIC of the third-party encoder.
+    """
+    from transformers import T5Config, T5EncoderModel
+    cfg = T5Config(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8,
+                   relative_attention_num_buckets=32, relative_attention_max_distance=128,
+                   dropout_rate=0.1, layer_norm_epsilon=1e-6, feed_forward_proj="relu")
+    m = T5EncoderModel(cfg).eval()
+    synth.fill_module_(m, seed=0, prefix="t5.")
+    ids = torch.from_numpy(synth._rng("inputs.t5ids", 0).integers(1, 32128, size=(3, 24)))
+    lengths = [24, 9, 17]
+    mask = torch.zeros(3, 24, dtype=torch.int64)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1
+    ids = ids * mask                                             # pad id 0
+    out = m(input_ids=ids, attention_mask=mask, return_dict=True).last_hidden_state
+    np.savez(os.path.join(out_dir, "t5_encoder.npz"), ids=ids.numpy(), mask=mask.numpy(),
+             last_hidden_state=out.numpy())
+    man = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(out_dir, "state_dict_manifest_t5.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("t5_encoder:", out.shape, float(out.abs().max()))
+
+
+@torch.no_grad()
 def manifest(out_dir):
     """ state_dict key/shape manifest = the checkpoint-layout contract. """
     savi, wrapper = build_reference(num_slots=30, num_context=1, num_preds=19)
@@ -299,7 +328,7 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur", "t5"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -310,3 +339,5 @@ if __name__ == "__main__":
         uncond_fixtures(HERE)
     if "dinosaur" in what:
         dinosaur_fixtures(HERE)
+    if "t5" in what:
+        t5_fixtures(HERE)

@@ -114,8 +114,10 @@ def test_unconditioned_predictor_layouts():
         pred = setup_predictor(exp)
         got = {k: list(v.shape) for k, v in pred.state_dict().items()}
         assert got == man[name], name
-    with pytest.raises(NotImplementedError):
-        setup_predictor(default_exp_params(predictor_name="TextOCVP_T5"))
+    bad = default_exp_params(predictor_name="OCVPSeq")
+    bad["predictor"]["predictor_name"] = "NoSuchPredictor"
+    with pytest.raises(NameError):
+        setup_predictor(bad)
     # the reference wrapper demands caption tokens even for unconditioned predictors
     pred = setup_predictor(default_exp_params(num_slots=7, predictor_name="OCVPSeq"))
     with torch.no_grad(), pytest.raises(KeyError):
@@ -136,3 +138,18 @@ def test_dinosaur_layout_and_backbone_guard():
         assert k in model.state_dict(), k
     with torch.no_grad(), pytest.raises(NotImplementedError):
         model(mode="decomp", x=torch.zeros(1, 2, 3, 224, 224), num_imgs=2)    # ViT not vendored
+
+
+def test_t5_predictor_layout():
+    """ TextOCVP_T5: text_encoder.* keys are those of transformers.T5EncoderModel (t5-small) """
+    import json
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest_t5.json")))
+    pred = setup_predictor(default_exp_params(num_slots=7, predictor_name="TextOCVP_T5"))
+    sd = pred.state_dict()
+    got = {k[len("predictor.text_encoder."):]: list(v.shape) for k, v in sd.items()
+           if k.startswith("predictor.text_encoder.")}
+    assert got == man
+    assert "predictor.predictor.7.cross_attention.cross_attn.q.weight" in sd
+    assert not any(p.requires_grad for p in pred.predictor.text_encoder.parameters())
+    with torch.no_grad(), pytest.raises(KeyError):
+        pred(torch.zeros(1, 3, 7, 128), caption_tokens=torch.zeros(1, 4, dtype=torch.int64))

@@ -315,3 +315,31 @@ def test_dinosaur_decode_side_config4():
     ref_imgs, ref_feats, _ = O.mlp_patch_decoder(O.sub(sd, "decoder."), ref[0], img_size=224)
     assert max_abs(got["recons_feats"][0].cpu(), ref_feats) < 2e-4
     assert max_abs(got["recons_imgs"][0].cpu(), ref_imgs) < 5e-6
+
+
+@torch.no_grad()
+def test_textocvp_t5_against_transformers_golden_and_oracle():
+    """ TextOCVP_T5: T5-small text encoder on the kernels + rollout conditioned on it """
+    g = load_golden("t5_encoder.npz")
+    exp = default_exp_params(num_slots=7, num_context=2, num_preds=3, predictor_name="TextOCVP_T5")
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(pred.predictor.text_encoder, prefix="t5.")
+    synth.fill_module_(pred.predictor.predictor, prefix="pred.predictor.predictor.")
+    synth.fill_module_(pred.predictor.mlp_in, prefix="pred.predictor.mlp_in.")
+    synth.fill_module_(pred.predictor.mlp_out, prefix="pred.predictor.mlp_out.")
+    psd = {k: v.clone() for k, v in pred.state_dict().items()}
+    pred = pred.to(DEV)
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    text = pred.predictor.text_encoder(input_ids=gpu(ids), attention_mask=gpu(mask))
+    assert max_abs(text.cpu(), g["last_hidden_state"]) < 5e-5
+    # rollout conditioned on the T5 embeddings vs the oracle predictor step
+    hist = synth.synth_tensor("unit.hist6", (3, 6, 7, 128), "normal")
+    got = pred(gpu(hist), caption_tokens=gpu(ids), attn_masks=gpu(mask))
+    p = O.sub(psd, "predictor.")
+    text_ref = torch.from_numpy(g["last_hidden_state"])
+    window, ref = hist[:, :2].clone(), []
+    for t in range(3):
+        cur = O.text_ocvp_step(p, window, text_ref)
+        window = torch.cat([window, cur.unsqueeze(1)], dim=1)
+        ref.append(cur)
+    assert max_abs(got.cpu(), torch.stack(ref, dim=1)) < 1e-4

@@ -23,6 +23,7 @@ struct MhaArgs {
     float scale;
     const int32_t* key_len;
     void* Osplit; int nsplit;      // optional (B*Tq, nsplit, H*dh) bf16-plane output instead of O
+    const float* bias;             // optional additive score bias (H, Tq, Tk), e.g. T5 relative positions
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -107,7 +108,12 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb * 32 + acc_row(r, h);
-            s[r] = (key < kv_len) ? s[r] * p.scale : NEG_BIG;
+            float sv = s[r] * p.scale;
+            if (p.bias && key < kv_len) {
+                const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
+                sv += p.bias[((size_t)head * p.Tq + q) * p.Tk + key];
+            }
+            s[r] = (key < kv_len) ? sv : NEG_BIG;
             bm = fmaxf(bm, s[r]);
         }
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
 
 static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       float* O, int ldo, void* Osplit, int nsplit, int B, int H, int Tq, int Tk,
-                      int dh, float scale, const int32_t* key_len, void* stream) {
+                      int dh, float scale, const int32_t* key_len, void* stream,
+                      const float* bias = nullptr) {
     TOCVP_CHECK_ARG(Q && K && V && (O || Osplit));
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq > 0 && Tk > 0);
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
@@ -186,7 +193,7 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
         (Osplit && !tocvp_aligned16(Osplit)))
         return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
-    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit};
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias};
     dim3 grid((Tq + 127) / 128, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dh == 64)
@@ -209,4 +216,13 @@ extern "C" int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int
     TOCVP_CHECK_ARG(Osplit != nullptr);
     return mha_launch(Q, ldq, K, ldk, V, ldv, nullptr, 0, Osplit, nsplit, B, H, Tq, Tk, dh, scale,
                       key_len, stream);
+}
+
+extern "C" int tocvp_mha_bias_f32(const float* Q, int ldq, const float* K, int ldk, const float* V,
+                                  int ldv, float* O, int ldo, int B, int H, int Tq, int Tk, int dh,
+                                  float scale, const int32_t* key_len, const float* bias,
+                                  void* stream) {
+    TOCVP_CHECK_ARG(bias != nullptr);
+    return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, Tq, Tk, dh, scale, key_len,
+                      stream, bias);
 }

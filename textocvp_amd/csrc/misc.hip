@@ -72,6 +72,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * gamma   (no mean subtraction, no bias)
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      float* __restrict__ y, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[4];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D)
+            *reinterpret_cast<f32x4*>(y + (size_t)row * D + c) =
+                v[i] * rstd * *reinterpret_cast<const f32x4*>(gamma + c);
+    }
+}
+
+// out[r, :] = table[ids[r], :]   (token embedding lookup, ids clamped into the table)
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids,
+                                                        const float* __restrict__ table,
+                                                        float* __restrict__ out, int rows, int D,
+                                                        int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int c = lane * 4; c < D; c += 256)
+        *reinterpret_cast<f32x4*>(out + (size_t)row * D + c) =
+            *reinterpret_cast<const f32x4*>(table + (size_t)id * D + c);
+}
+
 // ------------------------------------------------------------------------------------------
 // GRUCell gates
 // ------------------------------------------------------------------------------------------
@@ -317,5 +361,25 @@ extern "C" int tocvp_slot_init_f32(const float* mu, const float* sigma, const fl
     if (rows == 0) return TOCVP_OK;
     hipLaunchKernelGGL(slot_init_kernel, dim3(blocks_for((long)rows * D, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), mu, sigma, noise, out, (long)rows * D, D);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_rmsnorm_f32(const float* x, const float* gamma, float* y, int rows, int D,
+                                 float eps, void* stream) {
+    TOCVP_CHECK_ARG(x && gamma && y && rows >= 0 && D > 0 && D <= 1024 && (D & 3) == 0);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma)) return TOCVP_EALIGN;
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, gamma, y, rows, D, eps);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_embedding_f32(const int64_t* ids, const float* table, float* out, int rows,
+                                   int D, int vocab, void* stream) {
+    TOCVP_CHECK_ARG(ids && table && out && rows >= 0 && D > 0 && (D & 3) == 0 && vocab > 0);
+    if (!tocvp_aligned16(table) || !tocvp_aligned16(out)) return TOCVP_EALIGN;
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(embedding_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ids, table, out, rows, D, vocab);
     return tocvp_launch_status();
 }

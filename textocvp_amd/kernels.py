@@ -108,6 +108,16 @@ _SIGNATURES = {
     "tocvp_bilinear_resize_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_rmsnorm_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p]),
+    "tocvp_embedding_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_mha_bias_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_slot_init_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -357,7 +367,7 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
     return y.reshape(x.shape)
 
 
-def mha(q, k, v, heads, scale, key_len=None, out_split=0):
+def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     """
     q: (B, Tq, E) view with unit last stride (may be a column slice of a fused projection);
     k, v: (B, Tk, E) likewise.  Returns (B, Tq, E) contiguous fp32, or a SplitAct if out_split.
@@ -370,6 +380,13 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0):
         assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), (name, t.stride())
     if key_len is not None:
         assert key_len.dtype == torch.int32 and key_len.is_cuda and key_len.numel() == B
+    if bias is not None:
+        assert not out_split and bias.is_contiguous() and tuple(bias.shape) == (heads, Tq, Tk)
+        o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
+        _check(lib().tocvp_mha_bias_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v),
+                                        v.stride(1), _ptr(o), E, B, heads, Tq, Tk, dh, float(scale),
+                                        _ptr(key_len), _ptr(bias), _stream()), "tocvp_mha_bias_f32")
+        return o
     if out_split:
         o = torch.empty((B * Tq, out_split, E), device=q.device, dtype=torch.bfloat16)
         _check(lib().tocvp_mha_split_bf16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v),
@@ -627,3 +644,27 @@ def bilinear_resize_nhwc_to_nchw(x, channels, out_h, out_w):
     _check(lib().tocvp_bilinear_resize_f32(_ptr(x), _ptr(y), n, channels, Cs, SH, SW, out_h, out_w,
                                            _stream()), "tocvp_bilinear_resize_f32")
     return y
+
+
+def rms_norm(x, gamma, eps):
+    """ T5LayerNorm over the last axis """
+    _dev_f32(x, "x")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    _check(lib().tocvp_rmsnorm_f32(_ptr(x2), _ptr(gamma), _ptr(y), x2.shape[0], D, float(eps),
+                                   _stream()), "tocvp_rmsnorm_f32")
+    return y.reshape(x.shape)
+
+
+def embedding(ids, table):
+    """ ids int64 (...,) on device, table (V, D) -> (..., D) """
+    assert ids.dtype == torch.int64 and ids.is_cuda
+    ids = ids.contiguous()
+    V, D = table.shape
+    out = torch.empty((*ids.shape, D), device=table.device, dtype=torch.float32)
+    _check(lib().tocvp_embedding_f32(_ptr(ids), _ptr(table), _ptr(out), ids.numel(), D, V, _stream()),
+           "tocvp_embedding_f32")
+    return out

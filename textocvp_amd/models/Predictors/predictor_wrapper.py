@@ -56,7 +56,10 @@ class PredictorWrapper(nn.Module):
         if caption is None:
             raise KeyError("'caption_tokens' must be provided for the text-encoder.")
         if "T5" in self.predictor_name:
-            raise NotImplementedError("TextOCVP_T5 needs hub weights (parity unpinned, SURVEY 8c)")
+            attention_mask = kwargs.get("attn_masks", None)
+            if attention_mask is None:
+                raise KeyError("'attn_masks' must be provided for T5 Predictor")
+            return self.predictor.text_encoder(input_ids=caption, attention_mask=attention_mask)
         if "CustomTF" in self.predictor_name:
             lengths = kwargs.get("caption_lengths", None)
             if lengths is None:

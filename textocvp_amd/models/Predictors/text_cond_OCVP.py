@@ -3,8 +3,10 @@ Text-conditioned object-centric predictor.  Reference: models/Predictors/text_co
 (BaseTextOCVP :21-119, forward :79-105; TextOCVP_CustomTF :123-137).
 """
 
+import math
 import os
 
+import torch
 import torch.nn as nn
 
 from ... import kernels as K
@@ -13,7 +15,7 @@ from ..Blocks.model_blocks import TemporalPositionalEncoding
 from ..Blocks.model_utils import require_inference
 from ..EncodersDecoders.text_encoders import TransformerTextEncoder
 
-__all__ = ["TextOCVP_CustomTF"]
+__all__ = ["TextOCVP_CustomTF", "TextOCVP_T5", "T5TextEncoder"]
 
 
 class BaseTextOCVP(nn.Module):
@@ -91,3 +93,97 @@ class TextOCVP_CustomTF(BaseTextOCVP):
         self.text_encoder = TransformerTextEncoder(
             input_dim=p.get("input_dim"), num_layers=p.get("num_layers"),
             num_heads=p.get("num_heads"), output_dim=self.token_dim, vocab_size=p.get("vocab_size"))
+
+
+def _t5_relative_buckets(L, num_buckets, max_distance, device):
+    """ bidirectional T5 bucket index of (key - query) for an L x L grid (integer bookkeeping) """
+    pos = torch.arange(L, device=device)
+    rel = pos[None, :] - pos[:, None]                       # key - query
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    rel = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(rel.float().clamp(min=1) / max_exact)
+                         / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, nb - 1))
+    return out + torch.where(rel < max_exact, rel, large)
+
+
+class T5TextEncoder(nn.Module):
+    """
+    Encoder of ``t5-small`` as used by TextOCVP_T5 (reference text_cond_OCVP.py:141-151 calls
+    ``T5EncoderModel.from_pretrained("t5-small")``, predictor_wrapper.py:101-111 reads
+    ``last_hidden_state``).  A randomly initialised ``transformers.T5EncoderModel`` is the PARAMETER
+    CONTAINER (identical state_dict keys, so the pretrained / fine-tuned weights of a reference
+    checkpoint load unchanged; nothing is downloaded); the arithmetic runs on the HIP kernels:
+    embedding gather, RMS LayerNorm, bias-free projections, attention with T5's bucketed
+    relative-position bias (scale 1, key-padding from the attention mask), ReLU feed-forward.
+    """
+
+    def __init__(self):
+        super().__init__()
+        from transformers import T5Config, T5EncoderModel
+        cfg = T5Config(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8,
+                       relative_attention_num_buckets=32, relative_attention_max_distance=128,
+                       dropout_rate=0.1, layer_norm_epsilon=1e-6, feed_forward_proj="relu")
+        self.t5 = T5EncoderModel(cfg)
+        self.cfg = cfg
+
+    def forward(self, input_ids, attention_mask):
+        """ ids (B, L) int64, mask (B, L) {0,1} -> last_hidden_state (B, L, 512) """
+        enc = self.t5.encoder
+        dev = enc.embed_tokens.weight.device
+        ids = input_ids.to(dev)
+        B, L = ids.shape
+        key_len = attention_mask.to(dev).sum(dim=1).to(torch.int32).contiguous()
+        H, E = self.cfg.num_heads, self.cfg.d_model
+        rel = enc.block[0].layer[0].SelfAttention.relative_attention_bias.weight     # (buckets, H)
+        buckets = _t5_relative_buckets(L, self.cfg.relative_attention_num_buckets,
+                                       self.cfg.relative_attention_max_distance, dev)
+        bias = rel.detach()[buckets].permute(2, 0, 1).contiguous()                   # (H, L, L) gather
+        eps = self.cfg.layer_norm_epsilon
+        h = K.embedding(ids, enc.embed_tokens.weight)
+        for blk in enc.block:
+            att, ff = blk.layer[0], blk.layer[1]
+            sa = att.SelfAttention
+            n = K.rms_norm(h, att.layer_norm.weight, eps)
+            q, k_, v = K.linear(n, sa.q.weight), K.linear(n, sa.k.weight), K.linear(n, sa.v.weight)
+            ctx = K.mha(q, k_, v, H, 1.0, key_len=key_len, bias=bias)
+            h = K.linear(ctx, sa.o.weight, residual=h)
+            n = K.rms_norm(h, ff.layer_norm.weight, eps)
+            mid = K.linear(n, ff.DenseReluDense.wi.weight, act=K.ACT_RELU)
+            h = K.linear(mid, ff.DenseReluDense.wo.weight, residual=h)
+        return K.rms_norm(h, enc.final_layer_norm.weight, eps)
+
+
+class TextOCVP_T5(BaseTextOCVP):
+    """ TextOCVP with the (frozen) T5-small text encoder (text_cond_OCVP.py:141-151). """
+
+    def _instantiate_text_encoder(self):
+        self.text_encoder = T5TextEncoderAdapter()
+        self.t5_token_dim = 512
+
+
+class T5TextEncoderAdapter(T5TextEncoder):
+    """
+    Exposes the HF module tree directly under ``text_encoder`` so the state_dict keys read
+    ``text_encoder.shared.weight`` / ``text_encoder.encoder.block...`` exactly like the reference,
+    where ``text_encoder`` IS the T5EncoderModel.
+    """
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        from transformers import T5Config, T5EncoderModel
+        cfg = T5Config(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8,
+                       relative_attention_num_buckets=32, relative_attention_max_distance=128,
+                       dropout_rate=0.1, layer_norm_epsilon=1e-6, feed_forward_proj="relu")
+        hf = T5EncoderModel(cfg)
+        self.cfg = cfg
+        self.shared = hf.shared
+        self.encoder = hf.encoder
+        for p_ in self.parameters():
+            p_.requires_grad_(False)                                   # freeze_params (:149)
+
+    @property
+    def t5(self):
+        return self

@@ -12,7 +12,7 @@ import torch
 from .models.SAVi import SAVi
 from .models.ExtendedDINOSAUR import ExtendedDINOSAUR
 from .models.Predictors.predictor_wrapper import PredictorWrapper
-from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
+from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF, TextOCVP_T5
 from .models.Predictors.OCVP import OCVPSeq, VanillaTransformerPredictor
 
 __all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params",
@@ -72,6 +72,10 @@ def default_exp_params(num_slots=8, num_context=1, num_preds=9, input_buffer_siz
     model["num_slots"] = num_slots
     if predictor_name == "TextOCVP_CustomTF":
         predictor = copy.deepcopy(_PREDICTOR_DEFAULT)
+    elif predictor_name == "TextOCVP_T5":
+        predictor = copy.deepcopy(_PREDICTOR_DEFAULT)
+        predictor["predictor_name"] = "TextOCVP_T5"
+        predictor["predictor_params"]["text_encoder_params"] = {}
     else:
         predictor = {"predictor_name": predictor_name, "predictor_params": dict(_UNCOND_DEFAULT)}
     return {
@@ -100,18 +104,19 @@ def setup_predictor(exp_params):
     model_params = exp_params["model"]["model_params"]
     name = exp_params["predictor"]["predictor_name"]
     pp = exp_params["predictor"]["predictor_params"]
-    if name == "TextOCVP_CustomTF":
+    if name in ("TextOCVP_CustomTF", "TextOCVP_T5"):
         inner = copy.deepcopy(pp["predictor_params"])
         inner["input_buffer_size"] = exp_params["prediction_params"]["input_buffer_size"]
-        core = TextOCVP_CustomTF(slot_dim=model_params["slot_dim"], predictor_params=inner,
-                                 fusion_params=pp.get("fusion_params"),
-                                 text_encoder_params=pp.get("text_encoder_params"))
+        cls = TextOCVP_CustomTF if name == "TextOCVP_CustomTF" else TextOCVP_T5
+        core = cls(slot_dim=model_params["slot_dim"], predictor_params=inner,
+                   fusion_params=pp.get("fusion_params"),
+                   text_encoder_params=pp.get("text_encoder_params"))
     elif name in ("VanillaTransformer", "OCVPSeq"):
         cls = VanillaTransformerPredictor if name == "VanillaTransformer" else OCVPSeq
         core = cls(num_slots=model_params["num_slots"], slot_dim=model_params["slot_dim"],
                    input_buffer_size=exp_params["prediction_params"]["input_buffer_size"], **pp)
     else:
-        raise NotImplementedError(f"predictor {name!r} is not built (TextOCVP_T5 needs hub weights)")
+        raise NameError(f"Predictor '{name}' not in recognized predictors")
     return PredictorWrapper(exp_params=exp_params, predictor=core)
 
 

@@ -75,6 +75,9 @@ def _param_values(name, shape, seed):
         # residual predictor: keep the per-step slot update small so a 19-step rollout stays O(1)
         return synth_array(name, shape, "uniform", scale=0.02 * math.sqrt(6.0 / shape[1]),
                            seed=seed)
+    if name.endswith("SelfAttention.q.weight"):
+        # T5 attention has no 1/sqrt(d_kv) factor (it lives in the query init): keep logits O(1)
+        return synth_array(name, shape, "uniform", scale=math.sqrt(6.0 / shape[1]) / 8.0, seed=seed)
     if "bias" in last:
         return synth_array(name, shape, "uniform", scale=0.1, seed=seed)
     if len(shape) == 1:
