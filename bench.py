@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TOCVP_BENCH_BATCH", 32)),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TOCVP_BENCH_BATCH", 128)),
                     help="sequences per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

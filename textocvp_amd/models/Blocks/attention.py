@@ -180,6 +180,22 @@ class MultiHeadSelfAttention(MetaAttention):
         return K.linear(o, self.out_projection[0].weight, residual=residual)
 
 
+    def forward_last(self, x, n_last, residual_last):
+        """
+        Self-attention evaluated only for the LAST ``n_last`` query tokens of every sequence (keys and
+        values still cover all tokens): x (B, T, E) -> (B, n_last, E).  Used by the predictor's final
+        layer, whose output is consumed for the newest frame only (text_cond_OCVP.py:101-103), so the
+        query / output projections of the other T - n_last tokens are never needed.  Exact.
+        """
+        B, T, E = x.shape
+        w_kv = self._derived.get("w_kv", [self.k.weight, self.v.weight],
+                                 lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
+        kv = K.linear(x, w_kv)                                            # (B, T, 2E)
+        q = K.linear(x[:, T - n_last:].contiguous(), self.q.weight)       # (B, n_last, E)
+        o = K.mha(q, kv[..., :E], kv[..., E:], self.num_heads, (E // self.num_heads) ** -0.5)
+        return K.linear(o, self.out_projection[0].weight, residual=residual_last)
+
+
 class MultiHeadCrossAttention(MetaAttention):
     """
     Text-to-slot cross-attention (reference :269-319).  Keys/values depend only on the text and
@@ -289,6 +305,18 @@ class AdaptedEncoderBlock(TransformerBlock):
         y = self.attn(_ln(x, self.layernorm_query, split=_ns(E)), residual=x)
         z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
         return _mlp(_ln(z, self.layernorm_mlp, split=_ns(E, self.mlp_size)), self.mlp, residual=y)
+
+    def forward_last(self, x, text_embeddings, n_last, text_kv=None):
+        """
+        Same block, output for the last ``n_last`` tokens of every sequence only: (B, T, E) ->
+        (B, n_last, E).  Only self-attention mixes tokens; everything after it is row-wise, so it is
+        evaluated on the n_last rows that are consumed.  Bit-for-bit the rows forward() would give.
+        """
+        B, T, E = x.shape
+        x_last = x[:, T - n_last:].contiguous()
+        y = self.attn.forward_last(_ln(x, self.layernorm_query), n_last, residual_last=x_last)
+        z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
+        return _mlp(_ln(z, self.layernorm_mlp), self.mlp, residual=y)
 
     def condition_slots_given_caption(self, slots_to_condition, text_embeddings, text_kv=None):
         return self.cross_attention(queries=slots_to_condition, feats=text_embeddings,

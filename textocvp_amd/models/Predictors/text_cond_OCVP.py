@@ -54,6 +54,7 @@ class BaseTextOCVP(nn.Module):
         self._text_cache = None
         # arithmetic of the predictor GEMMs: "fp32" | "bf16x3" | "bf16x6" (kernels.gemm_precision)
         self.gemm_precision = os.environ.get("TOCVP_PREDICTOR_PRECISION", "bf16x6")
+        self.last_layer_newest_frame_only = os.environ.get("TOCVP_LAST_LAYER_SUBSET", "1") != "0"
 
     def _instantiate_text_encoder(self):
         raise NotImplementedError("'BaseTextOCVP' does not implement '_instantiate_text_encoder'...")
@@ -78,9 +79,16 @@ class BaseTextOCVP(nn.Module):
             tokens = K.linear(slots, self.mlp_in.weight, self.mlp_in.bias,
                               rowvec=self.pe.rows(w, slots.device), rv_div=Ks, rv_flip=True)
             tokens = tokens.reshape(B, w * Ks, self.token_dim)
-            for blk, kv in zip(self.predictor, text_kv):
-                tokens = blk(tokens, text_embeddings, text_kv=kv)
-            last = tokens.reshape(B, w, Ks, self.token_dim)[:, -1].contiguous()
+            nblk = len(self.predictor)
+            for i, (blk, kv) in enumerate(zip(self.predictor, text_kv)):
+                if i == nblk - 1 and self.last_layer_newest_frame_only:
+                    # only tokens[:, -1] (the newest frame) is read below: the final layer computes
+                    # just those K rows (keys / values still span the whole window)
+                    last = blk.forward_last(tokens, text_embeddings, Ks, text_kv=kv)
+                else:
+                    tokens = blk(tokens, text_embeddings, text_kv=kv)
+            if not self.last_layer_newest_frame_only or nblk == 0:
+                last = tokens.reshape(B, w, Ks, self.token_dim)[:, -1].contiguous()
             return K.linear(last, self.mlp_out.weight, self.mlp_out.bias,
                             residual=slots[:, -1].contiguous() if self.residual else None)
 
