@@ -11,17 +11,35 @@ Rollout evaluation harness: this repo's counterpart of the reference's ``Evaluat
     (RCCL over xGMI on GPUs, gloo in the CPU tests); no communication inside the rollout.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
 __all__ = ["forward_eval", "psnr_per_frame", "shard_batches", "gather_metrics"]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 @torch.no_grad()
-def forward_eval(decomp_model, predictor, videos, num_context, num_preds, **others):
+def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overlap_decode=None,
+                 **others):
     """
     videos (B, L, C, H, W) in [0,1]; ``others`` carries caption_tokens / caption_lengths
-    (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets).
+    (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets, masks).
+
+    overlap_decode (default: env TOCVP_OVERLAP_DECODE, on): frame t is decoded on a SECOND HIP stream
+    as soon as rollout step t is enqueued.  The rollout is a chain of short dependent kernels that
+    cannot fill 256 CUs (especially while the window is short); the MFMA-bound decoder convolutions
+    of already-predicted frames run in the gaps.  Same kernels, same arithmetic, same results.
     """
     B, L, C, H, W = videos.shape
     if L < num_context + num_preds:
@@ -30,13 +48,36 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, **othe
     out_model = decomp_model(mode="decomp", x=videos, num_imgs=num_context + num_preds,
                              decode=False, **others)
     slot_history = out_model["slot_history"]
-    pred_slots = predictor(slot_history, **others)
-    out_dec = decomp_model(mode="decode",
-                           slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
-    pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
+    if overlap_decode is None:
+        overlap_decode = os.environ.get("TOCVP_OVERLAP_DECODE", "1") != "0"
+    if not (overlap_decode and slot_history.is_cuda):
+        pred_slots = predictor(slot_history, **others)
+        out_dec = decomp_model(mode="decode",
+                               slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
+        pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
+        masks = out_dec["masks"]
+    else:
+        main = torch.cuda.current_stream()
+        side = _side_stream(slot_history.device)
+        per_step = [None] * num_preds
+
+        def decode_step(t, pred_t):
+            ready = torch.cuda.Event()
+            ready.record(main)
+            pred_t.record_stream(side)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                per_step[t] = decomp_model(mode="decode", slots=pred_t)
+        side.wait_stream(main)                                    # decoder weights / caches are ready
+        pred_slots = predictor(slot_history, step_callback=decode_step, **others)
+        main.wait_stream(side)
+        imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
+        masks = torch.stack([d["masks"] for d in per_step], dim=1)
+        masks = masks.reshape(B * num_preds, *masks.shape[2:])
+        pred_imgs = imgs.clamp(0, 1)
     targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)
     return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,
-            "targets": targets, "masks": out_dec["masks"]}
+            "targets": targets, "masks": masks}
 
 
 def psnr_per_frame(preds, targets, eps=1e-8):

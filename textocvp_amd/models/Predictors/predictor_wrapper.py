@@ -36,8 +36,13 @@ class PredictorWrapper(nn.Module):
         if self.input_buffer_size is None:
             self.input_buffer_size = self.num_context
 
-    def forward(self, slot_history, num_preds=None, **kwargs):
-        """ slot_history (B, T, K, D) -> pred_slots (B, num_preds, K, D) """
+    def forward(self, slot_history, num_preds=None, step_callback=None, **kwargs):
+        """
+        slot_history (B, T, K, D) -> pred_slots (B, num_preds, K, D).
+        ``step_callback(t, pred_t)`` (extension) is invoked right after step t is enqueued, so a
+        consumer (the evaluator's decoder on a second HIP stream) can start on frame t while the
+        rollout continues.
+        """
         self.teacher_force = self.exp_params["prediction_params"]["teacher_force"]
         num_preds = num_preds if num_preds is not None else self.num_preds
         text_embeddings = self.encode_text_caption(**kwargs)
@@ -49,6 +54,8 @@ class PredictorWrapper(nn.Module):
             nxt = slot_history[:, self.num_context + t] if self.teacher_force else cur
             window = self._update_buffer_size(torch.cat([window, nxt.unsqueeze(1)], dim=1))
             preds.append(cur)
+            if step_callback is not None:
+                step_callback(t, cur)
         return torch.stack(preds, dim=1)
 
     def encode_text_caption(self, **kwargs):
