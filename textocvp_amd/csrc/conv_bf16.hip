@@ -187,18 +187,50 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
     }
   }  // pass
 
+    if (NW == 4) {
+        // Epilogue through LDS: the accumulator layout gives each lane ONE output channel of 16
+        // pixels, i.e. 64 four-byte stores per lane in 128-byte segments (measured ~1.5 TB/s).
+        // Staging the wave's 64 pixels x 64 channels tile in LDS (the halo / weight images are dead
+        // after the last tap's barrier) turns them into 16 dwordx4 stores per lane, each wave
+        // instruction writing 1 KiB of contiguous NHWC output (4 pixels x 256 B).
+        constexpr int SS = C + 4;                                  // padded floats per pixel
+        static_assert(4 * 64 * SS * 4 <= IH * IW * ROWB + 2 * C * ROWB, "staging must fit the LDS image");
+        float* stage = reinterpret_cast<float*>(lds) + wave * (64 * SS);
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        const float bv = p.bias[(wcol + n) * 32 + l31];
+        for (int n = 0; n < NB; ++n) {
+            const float bv = p.bias[n * 32 + l31];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int oy = ty0 + 2 * wrow + m;
-            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C + (wcol + n) * 32 + l31;
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[m][n][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                yrow[(size_t)acc_row(r, h) * C] = v;
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][n][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    stage[(m * 32 + acc_row(r, h)) * SS + n * 32 + l31] = v;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* ybase = p.y + (((size_t)img * p.H + ty0 + 2 * wrow) * p.W + tx0) * C;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = lane + 64 * it;
+            const int px = idx >> 4, c4 = (idx & 15) * 4;          // pixel 0..63 of the wave, channel
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
+            *reinterpret_cast<f32x4*>(ybase + ((size_t)(px >> 5) * p.W + (px & 31)) * C + c4) = v;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const float bv = p.bias[(wcol + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = ty0 + 2 * wrow + m;
+                float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C + (wcol + n) * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][n][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    yrow[(size_t)acc_row(r, h) * C] = v;
+                }
             }
         }
     }

@@ -127,6 +127,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         buf ^= 1;
     }
 
+    // fast epilogue (no row-vector): 32-row blocks of the wave tile staged in LDS (tiles are dead
+    // after the last barrier) and written / residual-read as dwordx4 rows (see gemm_bf16.hip)
+    constexpr int SS = WN + 4;
+    if (!p.rowvec && (p.ldc & 3) == 0 && (!p.R || (p.ldr & 3) == 0)) {
+        float* stage = lds + wave * (32 * SS);
+        constexpr int F4R = WN / 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * WN + j * 32 + l31;
+                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[acc_row(r, h) * SS + j * 32 + l31] = apply_act(acc[i][j][r] + bv, p.act);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * F4R) / 64; ++it) {
+                const int idx = lane + 64 * it;
+                const int rr = idx / F4R, c4 = (idx % F4R) * 4;
+                const int row = m0 + wm * WM + i * 32 + rr, col = n0 + wn * WN + c4;
+                if (row < p.M && col + 3 < p.N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
+                    if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                } else if (row < p.M) {
+                    for (int u = 0; u < 4; ++u)
+                        if (col + u < p.N) {
+                            float v = stage[rr * SS + c4 + u];
+                            if (p.R) v += p.R[(size_t)row * p.ldr + col + u];
+                            p.C[(size_t)row * p.ldc + col + u] = v;
+                        }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+
     // epilogue: lane owns column (l31) of each 32x32 block, 16 rows per block
 #pragma unroll
     for (int j = 0; j < NI; ++j) {

@@ -365,6 +365,42 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         __syncthreads();
     }
 
+    // ---- fast epilogue (no row-vector, fp32 output): stage each 32-row block of the wave's tile in
+    // LDS (the A images are dead after the loop's last barrier) and write it back as dwordx4 rows:
+    // 8 stores per lane per block, each wave instruction covering 4 rows x WN*4 contiguous bytes,
+    // instead of 32 four-byte stores in 128-byte segments; the residual is read the same way.
+    constexpr int SS = WN + 4;
+    constexpr bool STAGE_FITS = (NW * 32 * SS * 4) <= (2 * BM * ROWB);
+    if (STAGE_FITS && !p.rowvec && !p.c_split) {
+        float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SS);
+        constexpr int F4R = WN / 4;                                   // float4 per staged row
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * WN + j * 32 + l31;
+                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[acc_row(r, h) * SS + j * 32 + l31] = apply_act(acc[i][j][r] + bv, p.act);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * F4R) / 64; ++it) {
+                const int idx = lane + 64 * it;
+                const int rr = idx / F4R, c4 = (idx % F4R) * 4;
+                const int row = m0 + wm * WM + i * 32 + rr, col = n0 + wn * WN + c4;
+                if (row < p.M && col < p.N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
+                    if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
@@ -536,9 +572,10 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
     TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0);
     TOCVP_CHECK_ARG(a_split || lda >= K);
     TOCVP_CHECK_ARG(c_split || ldc >= N);
-    TOCVP_CHECK_ARG(R == nullptr || ldr >= N);
+    TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
     TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
+    TOCVP_CHECK_ARG(c_split || ((ldc & 3) == 0 && tocvp_aligned16(C)));
     if ((!a_split && (lda & 3)) || !tocvp_aligned16(A) || !tocvp_aligned16(Wfrag)) return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
     GemmArgs p{static_cast<const float*>(A), lda, static_cast<const __bf16*>(Wfrag), bias, R, ldr,
