@@ -192,9 +192,13 @@ int tocvp_conv5x5_f32(const float* x, const float* aux, int in_mode, const float
  *   in_mode / aux as in tocvp_conv5x5_f32.
  * ------------------------------------------------------------------------------------------- */
 int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout, int Cin, void* stream);
+/* same weights in MFMA-fragment order (25, 2 passes, 2 k-steps, 2 column blocks, 2 planes, 64 lanes, 8):
+ * the kernel then fetches B fragments straight from L1/L2 (no weight image in LDS, no barrier in
+ * the tap loop).  Pass either layout (or both; wfrag is preferred). */
+int tocvp_split_conv_weights_frag_bf16(const float* w, void* out, int Cout, int Cin, void* stream);
 int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode, const void* wsplit,
-                             const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
-                             int relu, void* stream);
+                             const void* wfrag, const float* bias, float* y, int nimg, int H, int W,
+                             int Cin, int Cout, int relu, void* stream);
 
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of

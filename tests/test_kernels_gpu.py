@@ -244,6 +244,11 @@ def test_conv5x5_bf16x3_accuracy(n):
     ref = ref.permute(0, 2, 3, 1)
     ws = k.split_conv_weights_bf16(w.to(DEV))
     got = k.conv5x5_bf16x3(x.to(DEV), ws, b.to(DEV), relu=True)
+    # weights-direct variant (fragment-order weights, no LDS weight image) must agree bit for bit:
+    # same products in the same order
+    got_wd = k.conv5x5_bf16x3(x.to(DEV), ws, b.to(DEV), relu=True,
+                              wfrag=k.split_conv_weights_frag_bf16(w.to(DEV)))
+    assert torch.equal(got, got_wd)
     err = (got.cpu().double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     print(f"bf16x3 conv: max abs err {err:.3e} at scale {scale:.3g}")

@@ -29,6 +29,7 @@ constexpr int C = 64;
 struct ConvArgs {
     const float* x; const float* aux; const unsigned char* wsplit; const float* bias; float* y;
     int nimg, H, W, relu;
+    const unsigned char* wfrag;   // weights in MFMA-fragment order (WD variants), else unused
 };
 
 __device__ __forceinline__ int border_class(int p, int n) {
@@ -52,9 +53,15 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
 // CCH = input channels resident per pass (64: one pass, 152 KB LDS, 1 workgroup / CU;
 //       32: two passes over the taps, 80.6 KB LDS -> 2 workgroups / CU, so one workgroup's tile
 //       staging / epilogue / barriers overlap the other's MFMAs).
-template <int MODE, int NW, int CCH>
+// WD = weights direct: B fragments come straight from global memory in MFMA-fragment order
+//      Wf[tap][pass][ks][nb][plane][lane] (one coalesced 1 KiB load per fragment, L1/L2 resident: the
+//      800 KB of split weights are shared by every workgroup), prefetched one tap ahead in registers.
+//      No weight image in LDS and NO barrier inside the 25-tap loop: the waves of a workgroup run
+//      free between the two channel passes.
+template <int MODE, int NW, int CCH, bool WD = false>
 __global__ __launch_bounds__(NW * 64, (CCH == 32 ? 2 : 1) * (NW / 4))
 void conv5x5_bf16x3_kernel(ConvArgs p) {
+    static_assert(!WD || (NW == 4 && CCH == 32), "weights-direct variant is built for 4 waves x 32 ch");
     constexpr int NT = NW * 64;            // threads
     constexpr int NB = 8 / NW;             // 32-channel output blocks per wave (2 or 1)
     constexpr int ROWB = 2 * CCH * 2 + 16; // LDS bytes per pixel / per output channel (hi | lo | pad)
@@ -107,7 +114,7 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
 
   for (int pass = 0; pass < NPASS; ++pass) {
     if (pass > 0) __syncthreads();          // everyone done with the previous pass's LDS images
-    wload(0, pass);
+    if (!WD) wload(0, pass);
     // ---- halo tile: fp32 -> (hi, lo) bf16 planes in LDS.
     // All global loads of the tile are issued back to back from clamped (always valid) addresses
     // and only then converted: a load-use-per-iteration loop would expose the full memory latency
@@ -150,9 +157,54 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
             *reinterpret_cast<bf16x4*>(in_s + pix * ROWB + CCH * 2 + c * 2) = lo;
         }
     }
-    wstore(0);
+    if (!WD) wstore(0);
     __syncthreads();
 
+    if (WD) {
+        bf16x8 fb0[2][NB][2], fb1[2][NB][2];                       // [ks][nb][plane]
+        auto gload_b = [&](bf16x8 (&fb)[2][NB][2], int tap) {
+            const unsigned char* base = p.wfrag + (size_t)(tap * NPASS + pass) * (2 * NB * 2) * 1024 +
+                                        lane * 16;               // uniform part + lane offset
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fb[ks][n][pl] = *reinterpret_cast<const bf16x8*>(
+                            base + ((ks * NB + n) * 2 + pl) * 1024);
+        };
+        auto compute = [&](const bf16x8 (&fb)[2][NB][2], int tap) {
+            const int dy = tap / 5, dx = tap % 5;
+            const unsigned char* a_base = in_s + ((2 * wrow + dy) * IW + l31 + dx) * ROWB + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32);
+                    al[m] = *reinterpret_cast<const bf16x8*>(a_base + m * IW * ROWB + ks * 32 + CCH * 2);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        acc[m][n] = mfma_bf16(al[m], fb[ks][n][0], acc[m][n]);
+                        acc[m][n] = mfma_bf16(ah[m], fb[ks][n][1], acc[m][n]);
+                        acc[m][n] = mfma_bf16(ah[m], fb[ks][n][0], acc[m][n]);
+                    }
+            }
+        };
+        gload_b(fb0, 0);
+        for (int tap = 0; tap < 25; tap += 2) {                    // prefetches unconditional + clamped
+            gload_b(fb1, min(tap + 1, 24));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fb0, tap);
+            gload_b(fb0, min(tap + 2, 24));
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 25) compute(fb1, tap + 1);
+        }
+    } else
     for (int tap = 0; tap < 25; ++tap) {
         const int buf = tap & 1;
         if (tap + 1 < 25) wload(tap + 1, pass);
@@ -186,6 +238,7 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
         __syncthreads();
     }
   }  // pass
+    if (WD) __syncthreads();   // no barrier in the tap loop: the halo image must be dead before restaging
 
     if (NW == 4) {
         // Epilogue through LDS: the accumulator layout gives each lane ONE output channel of 16
@@ -253,7 +306,31 @@ __global__ __launch_bounds__(256) void split_conv_weights_kernel(const float* __
     o[Cin + ci] = lo;
 }
 
+// (64, 64, 5, 5) fp32 -> fragment order Wf[tap][pass(2)][ks(2)][nb(2)][plane(2)][lane(64)][8] bf16
+__global__ __launch_bounds__(256) void split_conv_weights_frag_kernel(const float* __restrict__ w,
+                                                                      __bf16* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // over 25 * 64 * 64
+    if (i >= 25 * C * C) return;
+    const int ci = i % C, co = (i / C) % C, tap = i / (C * C);
+    const float v = w[((size_t)co * C + ci) * 25 + tap];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int pass = ci >> 5, ks = (ci >> 4) & 1, hh = (ci >> 3) & 1, j = ci & 7;
+    const int nb = co >> 5, c = co & 31;
+    const size_t frag = ((((size_t)tap * 2 + pass) * 2 + ks) * 2 + nb) * 2;    // + plane
+    out[((frag + 0) * 64 + hh * 32 + c) * 8 + j] = hi;
+    out[((frag + 1) * 64 + hh * 32 + c) * 8 + j] = lo;
+}
+
 }  // namespace
+
+extern "C" int tocvp_split_conv_weights_frag_bf16(const float* w, void* out, int Cout, int Cin,
+                                                  void* stream) {
+    TOCVP_CHECK_ARG(w && out && Cout == C && Cin == C);
+    hipLaunchKernelGGL(split_conv_weights_frag_kernel, dim3((25 * C * C + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out));
+    return tocvp_launch_status();
+}
 
 extern "C" int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout, int Cin,
                                              void* stream) {
@@ -265,17 +342,20 @@ extern "C" int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout
 }
 
 extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode,
-                                        const void* wsplit, const float* bias, float* y, int nimg,
-                                        int H, int W, int Cin, int Cout, int relu, void* stream) {
-    TOCVP_CHECK_ARG(x && wsplit && bias && y);
+                                        const void* wsplit, const void* wfrag, const float* bias,
+                                        float* y, int nimg, int H, int W, int Cin, int Cout, int relu,
+                                        void* stream) {
+    TOCVP_CHECK_ARG(x && (wsplit || wfrag) && bias && y);
     TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
     TOCVP_CHECK_ARG(Cin == C && Cout == C);
     TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0 && (W % TW) == 0);
     TOCVP_CHECK_ARG((size_t)nimg * (H / TH) * (W / TW) < 0x7fffffffu);
-    if (!tocvp_aligned16(x) || !tocvp_aligned16(wsplit) || (aux && !tocvp_aligned16(aux)))
+    if (!tocvp_aligned16(x) || (wsplit && !tocvp_aligned16(wsplit)) || (wfrag && !tocvp_aligned16(wfrag)) ||
+        (aux && !tocvp_aligned16(aux)))
         return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
-    ConvArgs a{x, aux, static_cast<const unsigned char*>(wsplit), bias, y, nimg, H, W, relu};
+    ConvArgs a{x, aux, static_cast<const unsigned char*>(wsplit), bias, y, nimg, H, W, relu,
+               static_cast<const unsigned char*>(wfrag)};
     const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variants: "8x64" (8 waves, one pass, 1 workgroup/CU), "4x64", "4x32" / "8x32" (two channel
@@ -295,6 +375,14 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
         else                                                                                      \
             hipLaunchKernelGGL((conv5x5_bf16x3_kernel<1, NW_, CCH_>), grid, dim3(NW_ * 64), 0, s, a); \
     } while (0)
+    if (wfrag && (variant == 432 || !wsplit)) {      // weights-direct variant (default when given)
+        if (in_mode == 0)
+            hipLaunchKernelGGL((conv5x5_bf16x3_kernel<0, 4, 32, true>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv5x5_bf16x3_kernel<1, 4, 32, true>), grid, dim3(256), 0, s, a);
+        return tocvp_launch_status();
+    }
+    TOCVP_CHECK_ARG(wsplit != nullptr);
     switch (variant) {
         case 864: TOCVP_LAUNCH_CONV(8, 64); break;
         case 464: TOCVP_LAUNCH_CONV(4, 64); break;

@@ -89,10 +89,12 @@ _SIGNATURES = {
         ctypes.c_void_p]),
     "tocvp_split_conv_weights_bf16": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_split_conv_weights_frag_bf16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_conv5x5_bf16x3_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_int, ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_metrics_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_psnr_ssim_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -562,7 +564,19 @@ def split_conv_weights_bf16(w):
     return out
 
 
-def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None):
+def split_conv_weights_frag_bf16(w):
+    """ (64, 64, 5, 5) fp32 -> MFMA-fragment-order split weights (25*2*2*2*2*64*8,) bf16 """
+    Cout, Cin = w.shape[:2]
+    out = torch.empty((25 * Cout * Cin * 2,), device=w.device, dtype=torch.bfloat16)
+    _check(lib().tocvp_split_conv_weights_frag_bf16(_ptr(w.contiguous()), _ptr(out), Cout, Cin,
+                                                    _stream()), "tocvp_split_conv_weights_frag_bf16")
+    return out
+
+
+_CONV_WD = os.environ.get("TOCVP_CONV_WD", "1") != "0"
+
+
+def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=None):
     """
     64->64 5x5 conv with split-bf16 (bf16x3) operands, fp32 NHWC in/out.
     collapsed=(cpos, S): layer-1 mode fed by the analytically collapsed decoder layer 0.
@@ -579,13 +593,15 @@ def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None):
         xin, aux, mode, dev = x, None, 0, x.device
     Cout = wsplit.shape[1]
     assert wsplit.dtype == torch.bfloat16 and wsplit.shape == (25, Cout, 2 * Cin)
+    if not _CONV_WD:
+        wfrag = None
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
 
     def run():
-        _check(lib().tocvp_conv5x5_bf16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wsplit), _ptr(bias),
-                                              _ptr(out), n, H, W, Cin, Cout, int(bool(relu)),
-                                              _stream()), "tocvp_conv5x5_bf16x3_f32")
+        _check(lib().tocvp_conv5x5_bf16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wsplit), _ptr(wfrag),
+                                              _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
+                                              int(bool(relu)), _stream()), "tocvp_conv5x5_bf16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
     else:

@@ -75,6 +75,11 @@ class ConvDecoder(nn.Module):
         return self._derived.get(f"ws{i}", [conv.weight],
                                  lambda: K.split_conv_weights_bf16(conv.weight))
 
+    def _split_frag(self, i):
+        conv = self.decoder[i].conv
+        return self._derived.get(f"wf{i}", [conv.weight],
+                                 lambda: K.split_conv_weights_frag_bf16(conv.weight))
+
     def _collapsed_layer0(self, pos_table):
         """ (cpos (H,W,C0), tapsum (25*C0, D)) for the current weights / position table """
         c0 = self.decoder[0].conv
@@ -120,7 +125,8 @@ class ConvDecoder(nn.Module):
                          and conv.weight.shape[1] == 64)
                 if split:
                     x = K.conv5x5_bf16x3(x, self._split(i), conv.bias, relu=True, out=out,
-                                         collapsed=(cpos, S) if i == 1 else None)
+                                         collapsed=(cpos, S) if i == 1 else None,
+                                         wfrag=self._split_frag(i))
                 elif i == 1:
                     x = K.conv5x5_collapsed(cpos, S, self._packed(1), conv.bias, relu=True, out=out)
                 else:
