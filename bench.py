@@ -37,6 +37,9 @@ PATH_GFLOP_PER_FRAME = 149.5             # reference algorithm, 
 
 ARITH = {
     ("fp32", "fp32"): "fp32",
+    ("bf16x3", "f16x3"): "split operands on the 16-bit matrix cores (decoder convs bf16x3 = hi/lo bf16 "
+                         "planes, predictor GEMMs f16x3 = hi/lo fp16 planes; 3 products each), fp32 "
+                         "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
     ("bf16x3", "bf16x6"): "bf16 split operands (decoder convs bf16x3, predictor GEMMs bf16x6), fp32 "
                           "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
 }

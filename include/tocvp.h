@@ -87,6 +87,12 @@ int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wf
                              const float* rowvec, int rv_div, int rv_mod, int rv_flip,
                              void* C, int c_split, int ldc, int M, int N, int K, int act,
                              void* stream);
+/* "f16x3": the same kernel with fp16 planes (x = hi + lo in fp16, 22 significant bits, products
+ * hh + hl + lh): fp32-class accuracy at HALF the MFMA count of bf16x6, valid while |x| < 65504. */
+int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* stream);
+int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
+                            const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
+                            int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);
 /*   a_split != 0: A is already split by its producer, (M, nsplit, K) bf16 planes (lda ignored);
  *   c_split != 0: C is written as (M, nsplit, N) bf16 planes for a following split GEMM
  *   (ldc ignored).  Splitting an activation once in its producer instead of once per column block

@@ -339,3 +339,47 @@ def test_slot_composite_and_bilinear():
     close(k.bilinear_resize_nhwc_to_nchw(x.to(DEV), 3, 42, 42), ref, tol=2e-6)
     ref_up = F.interpolate(x[..., :3].permute(0, 3, 1, 2), size=(60, 60), mode="bilinear", align_corners=False)
     close(k.bilinear_resize_nhwc_to_nchw(x.to(DEV), 3, 60, 60), ref_up, tol=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(30, 512, 512), (9600, 2048, 512), (301, 512, 2048)])
+def test_gemm_f16x3_is_fp32_class(M, N, K):
+    """ two fp16 planes, 3 products: must be as accurate as the exact-fp32 MFMA kernel """
+    k = _k()
+    x, w, b = rnd("sx", (M, K)), rnd("sw", (N, K), "uniform", K ** -0.5), rnd("sb", (N,))
+    x[0, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 6e-5, -1e-7, 5e-3, 90.0, -200.0])   # tiny + large values
+    x[1] = x[1] * 1e-3                       # a whole row of small activations (fp16-subnormal lo planes)
+    res = rnd("sres", (M, N))
+    ref = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()
+    got = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU, residual=res.to(DEV),
+                   precision="f16x3")
+    got32 = k.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU, residual=res.to(DEV))
+    err = (got.cpu().double() - ref).abs().max().item()
+    err32 = (got32.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"f16x3 gemm {M}x{N}x{K}: err {err:.2e} (fp32 mfma {err32:.2e}) at scale {scale:.3g}")
+    assert err < max(2.5 * err32, 2e-6 * scale)
+    # the small row on its own, without the residual: relative accuracy must hold at its own scale
+    small_ref = torch.relu(x[1:2].double() @ w.double().t() + b.double())
+    small = k.linear(x[1:2].to(DEV), w.to(DEV), b.to(DEV), act=k.ACT_RELU, precision="f16x3")
+    assert (small.cpu().double() - small_ref).abs().max().item() < 3e-6
+
+
+def test_gemm_f16x3_range_behaviour(monkeypatch):
+    """ outside |x| < 255 the fp16 planes saturate: 11-bit accuracy up to 511, finite (never inf/nan)
+    beyond; TOCVP_CHECK_RANGE turns the silent saturation into an error """
+    k = _k()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 128, generator=g)
+    w = torch.randn(64, 128, generator=g) * 0.1
+    x[3, 7] = 400.0
+    x[9, 1] = -5000.0
+    ref = x.double() @ w.double().t()
+    got = k.linear(x.to(DEV), w.to(DEV), precision="f16x3").cpu().double()
+    assert torch.isfinite(got).all()
+    rows = [r for r in range(64) if r not in (3, 9)]
+    assert (got[rows] - ref[rows]).abs().max().item() < 1e-5
+    assert (got[3] - ref[3]).abs().max().item() < 400 * 0.1 * 4 * 2 ** -11
+    monkeypatch.setattr(k, "_CHECK_RANGE", True)
+    with pytest.raises(k.TocvpError, match="out of range"):
+        k.linear(x.to(DEV), w.to(DEV), precision="f16x3")
+    k.linear(x[:3].contiguous().to(DEV), w.to(DEV), precision="f16x3")

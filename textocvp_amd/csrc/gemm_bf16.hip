@@ -41,6 +41,33 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit operand element of the split kernels.  bf16: 8 significant bits per plane (x3 -> ~2^-16,
+// x6 -> ~2^-23).  fp16: 11 significant bits per plane, so TWO planes already carry 22 bits and the
+// three products hh + hl + lh are fp32-class (~2^-22) at half the MFMA count of bf16x6 ("f16x3");
+// valid while |x| < 255 after the operand pre-scaling described at Elem<true>.
+template <bool F16> struct Elem;
+template <> struct Elem<false> {
+    using T = __bf16; using V8 = bf16x8; using V4 = bf16x4;
+    static constexpr float SA = 1.f, SW = 1.f;          // bf16 has the fp32 exponent range
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<true> {
+    using T = _Float16; using V8 = f16x8; using V4 = f16x4;
+    // The matrix core flushes fp16 SUBNORMAL inputs, i.e. a lo plane below 6.1e-5 would vanish
+    // (measured: 2e-4 drift of the rollout).  Operands are therefore pre-scaled by exact powers of
+    // two (undone in the epilogue): activations x 2^8 (fp32-class for |x| < 255, 11-bit up to 511,
+    // saturating beyond; the flush threshold drops to 2.4e-7 absolute), weights x 2^10 (|w| < 63).
+    static constexpr float SA = 256.f, SW = 1024.f;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 // NS planes, BM x BN x BK tile, WM x WN per wave, NW waves (4: one per SIMD, 8: two per SIMD so the
 // partner's MFMAs cover this wave's split / LDS-store / barrier phases), MINW = waves per SIMD the
 // register budget must allow (occupancy across workgroups).
@@ -198,8 +225,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_split_kernel(GemmArgs
 //     ds_write pipe was the limiter of the LDS-staged split kernels) and halves the LDS footprint.
 //     B fragments are prefetched one whole k-tile (2 k-steps) ahead in registers.
 // ------------------------------------------------------------------------------------------------
-template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool ASPLIT>
+template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool ASPLIT, bool F16>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs p) {
+    using E = Elem<F16>;
+    using ET = typename E::T;
+    using EV8 = typename E::V8;
+    using EV4 = typename E::V4;
     constexpr int BK = 32;
     constexpr int ACH = BM * NS * 4;                 // 16-byte chunks of a pre-split A tile
     constexpr int RAS = (ACH + NW * 64 - 1) / (NW * 64);
@@ -283,21 +314,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
             for (int i = 0; i < RA; ++i) {
                 unsigned char* dst = As + buf * BM * ROWB + (lr + RSTEP * i) * ROWB + lc * 2;
                 f32x4 rem = ra[i];
+                if (F16) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        rem[u] = rem[u] * E::SA;
+                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    bf16x4 piece;
+                    EV4 piece;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        piece[u] = (__bf16)rem[u];
+                        // fp16: every plane saturates instead of overflowing to inf, so |x| up to
+                        // 2 x 255 degrades gracefully (hi pinned at 65504, the rest in lo)
+                        piece[u] = (ET)(F16 ? __builtin_amdgcn_fmed3f(rem[u], -65504.f, 65504.f) : rem[u]);
                         rem[u] -= (float)piece[u];
                     }
-                    *reinterpret_cast<bf16x4*>(dst + s * BK * 2) = piece;
+                    *reinterpret_cast<EV4*>(dst + s * BK * 2) = piece;
                 }
             }
         }
     };
     // B fragments of one k-tile: [ks in tile][column block][plane]
-    auto gload_b = [&](bf16x8 (&b)[2][NI][NS], int kt) {
+    auto gload_b = [&](EV8 (&b)[2][NI][NS], int kt) {
         const char* base = w_bytes + (size_t)kt * (2 * NS * 64 * 16);    // uniform
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -305,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    b[ks][j][s] = *reinterpret_cast<const bf16x8*>(base + voff_b[j] +
+                    b[ks][j][s] = *reinterpret_cast<const EV8*>(base + voff_b[j] +
                                                                    (ks * NS + s) * 64 * 16);
     };
 
@@ -317,16 +355,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](const bf16x8 (&b)[2][NI][NS], int buf) {
+    auto compute = [&](const EV8 (&b)[2][NI][NS], int buf) {
         const unsigned char* a_base = As + buf * BM * ROWB + (wm * WM + l31) * ROWB + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[MI][NS];
+            EV8 a[MI][NS];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    a[i][s] = *reinterpret_cast<const bf16x8*>(a_base + i * 32 * ROWB + s * BK * 2 +
+                    a[i][s] = *reinterpret_cast<const EV8*>(a_base + i * 32 * ROWB + s * BK * 2 +
                                                                ks * 32);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -336,12 +374,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                     for (int sum = NS - 1; sum >= 0; --sum)
 #pragma unroll
                         for (int sa = 0; sa <= sum; ++sa)
-                            acc[i][j] = mfma_bf16(a[i][sa], b[ks][j][sum - sa], acc[i][j]);
+                            acc[i][j] = E::mfma(a[i][sa], b[ks][j][sum - sa], acc[i][j]);
         }
     };
 
     const int nk = p.K / BK;
-    bf16x8 b0[2][NI][NS], b1[2][NI][NS];
+    EV8 b0[2][NI][NS], b1[2][NI][NS];
     // Branch-free software pipeline (nk even, host-checked; prefetch indices clamped so the tail
     // re-fetches tile nk-1): A one k-tile ahead (registers -> LDS), weight fragments one k-tile
     // ahead in registers, two k-tiles per iteration so the register sets have static names.
@@ -382,7 +420,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                 const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    stage[acc_row(r, h) * SS + j * 32 + l31] = apply_act(acc[i][j][r] + bv, p.act);
+                    stage[acc_row(r, h) * SS + j * 32 + l31] =
+                        apply_act(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bv, p.act);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -412,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + acc_row(r, h);
                 if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] * (1.f / (E::SA * E::SW)) + bv;
                 if (p.rowvec) {
                     int idx = (row / p.rv_div) % p.rv_mod;
                     if (p.rv_flip) idx = p.rv_mod - 1 - idx;
@@ -421,10 +460,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                 v = apply_act(v, p.act);
                 if (p.R) v += p.R[(size_t)row * p.ldr + col];
                 if (p.c_split) {
-                    __bf16* cs = reinterpret_cast<__bf16*>(p.C) + (size_t)row * NS * p.N + col;
+                    ET* cs = reinterpret_cast<ET*>(p.C) + (size_t)row * NS * p.N + col;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        const __bf16 piece = (__bf16)v;
+                        const ET piece = (ET)v;
                         cs[(size_t)s * p.N] = piece;
                         v -= (float)piece;
                     }
@@ -437,9 +476,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
 }
 
 // W (N, K) fp32 -> fragment-order bf16 planes Wf[nb][ks][plane][lane][8]
+template <bool F16>
 __global__ __launch_bounds__(256) void split_weights_frag_kernel(const float* __restrict__ w,
-                                                                 __bf16* __restrict__ out, long n,
-                                                                 int K, int NS) {
+                                                                 typename Elem<F16>::T* __restrict__ out,
+                                                                 long n, int K, int NS) {
+    using ET = typename Elem<F16>::T;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const long row = i / K;
@@ -447,9 +488,10 @@ __global__ __launch_bounds__(256) void split_weights_frag_kernel(const float* __
     const int nb = (int)(row >> 5), c = (int)(row & 31);
     const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
     const int KS = K / 16;
-    float rem = w[i];
+    float rem = w[i] * Elem<F16>::SW;
+    if (F16) rem = fminf(fmaxf(rem, -65504.f), 65504.f);
     for (int s = 0; s < NS; ++s) {
-        const __bf16 piece = (__bf16)rem;
+        const ET piece = (ET)rem;
         out[((((size_t)nb * KS + ks) * NS + s) * 64 + (hh * 32 + c)) * 8 + j] = piece;
         rem -= (float)piece;
     }
@@ -479,16 +521,22 @@ int launch(const GemmArgs& p, hipStream_t s) {
     return tocvp_launch_status();
 }
 
-template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW>
+template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool F16 = false>
 int launch_wfrag(const GemmArgs& p, hipStream_t s) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     if (p.a_split)
-        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, true>),
+        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, true, F16>),
                            dim3(ntm * ntn), dim3(NW * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, false>),
+        hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<NS, BM, BN, WM, WN, NW, MINW, false, F16>),
                            dim3(ntm * ntn), dim3(NW * 64), 0, s, p);
     return tocvp_launch_status();
+}
+
+int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
+    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (big_tiles < 192) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
+    return launch_wfrag<2, 128, 128, 64, 64, 4, 2, true>(p, s);
 }
 
 template <int NS>
@@ -557,8 +605,8 @@ extern "C" int tocvp_split_weights_frag_bf16(const float* w, void* out, int N, i
     TOCVP_CHECK_ARG(w && out && N > 0 && K > 0 && (nsplit == 2 || nsplit == 3));
     TOCVP_CHECK_ARG((N % 32) == 0 && (K % 32) == 0);
     const long n = (long)N * K;
-    hipLaunchKernelGGL(split_weights_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out), n, K, nsplit);
+    hipLaunchKernelGGL(split_weights_frag_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       0, static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out), n, K, nsplit);
     return tocvp_launch_status();
 }
 
@@ -568,7 +616,7 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
                                         void* C, int c_split, int ldc, int M, int N, int K, int act,
                                         void* stream) {
     TOCVP_CHECK_ARG(A && Wfrag && C);
-    TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3);
+    TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3 || nsplit == 22);
     TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0);
     TOCVP_CHECK_ARG(a_split || lda >= K);
     TOCVP_CHECK_ARG(c_split || ldc >= N);
@@ -582,5 +630,23 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
                rowvec, rv_div, rv_mod, rv_flip, static_cast<float*>(C), ldc, M, N, K, act,
                a_split ? 1 : 0, c_split ? 1 : 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nsplit == 22) return dispatch_wfrag_f16(p, s);         // fp16 planes ("f16x3")
     return nsplit == 2 ? dispatch_wfrag<2>(p, s) : dispatch_wfrag<3>(p, s);
+}
+
+extern "C" int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* stream) {
+    TOCVP_CHECK_ARG(w && out && N > 0 && K > 0);
+    TOCVP_CHECK_ARG((N % 32) == 0 && (K % 32) == 0);
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(split_weights_frag_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<_Float16*>(out), n, K, 2);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
+                                       const float* R, int ldr, const float* rowvec, int rv_div,
+                                       int rv_mod, int rv_flip, void* C, int ldc, int M, int N, int K,
+                                       int act, void* stream) {
+    return tocvp_gemm_bf16wfrag_f32(A, 0, lda, Wfrag, 22, bias, R, ldr, rowvec, rv_div, rv_mod, rv_flip,
+                                    C, 0, ldc, M, N, K, act, stream);
 }

@@ -42,6 +42,12 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_split_weights_frag_f16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_gemm_f16wfrag_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_layernorm_split_bf16": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
@@ -207,7 +213,7 @@ def _dev_f32(t, name):
 # GEMM arithmetic mode: "fp32" (exact fp32 MFMA), "bf16x3" or "bf16x6" (split-bf16 operands)
 # --------------------------------------------------------------------------------------------
 _GEMM_PRECISION = "fp32"
-_NSPLIT = {"bf16x3": 2, "bf16x6": 3}
+_NSPLIT = {"bf16x3": 2, "bf16x6": 3, "f16x3": 22}     # 22 = two fp16 planes
 _SPLIT_CACHE = {}
 
 
@@ -215,7 +221,7 @@ class gemm_precision:
     """ context manager selecting the arithmetic of ``linear`` calls issued inside it """
 
     def __init__(self, mode):
-        if mode not in ("fp32", "bf16x3", "bf16x6"):
+        if mode not in ("fp32", "bf16x3", "bf16x6", "f16x3"):
             raise ValueError(f"unknown GEMM precision {mode!r}")
         self.mode = mode
 
@@ -230,6 +236,10 @@ class gemm_precision:
 
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
+# f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
+# fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
+F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
+_CHECK_RANGE = os.environ.get("TOCVP_CHECK_RANGE", "0") != "0"
 
 
 class SplitAct:
@@ -250,7 +260,8 @@ class SplitAct:
 
 def active_nsplit():
     """ planes per operand of the GEMM arithmetic selected by the enclosing gemm_precision() """
-    return _NSPLIT.get(_GEMM_PRECISION, 0) if _WFRAG else 0
+    ns = _NSPLIT.get(_GEMM_PRECISION, 0) if _WFRAG else 0
+    return ns if ns in (2, 3) else 0          # pre-split activations exist for the bf16 planes only
 
 
 def _split_weight(w, nsplit, frag=False):
@@ -264,6 +275,12 @@ def _split_weight(w, nsplit, frag=False):
         for k_ in [k_ for k_, v in _SPLIT_CACHE.items() if v[0]() is None]:
             del _SPLIT_CACHE[k_]
     N, K = w.shape
+    if nsplit == 22:
+        out = torch.empty((N, 2, K), device=w.device, dtype=torch.float16)
+        _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, K, _stream()),
+               "tocvp_split_weights_frag_f16")
+        _SPLIT_CACHE[key] = (weakref.ref(w), (w._version, w.data_ptr()), out)
+        return out
     out = torch.empty((N, nsplit, K), device=w.device, dtype=torch.bfloat16)
     if frag:
         _check(lib().tocvp_split_weights_frag_bf16(_ptr(w), _ptr(out), N, K, nsplit, _stream()),
@@ -312,6 +329,8 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         assert rowvec.is_contiguous() and rowvec.shape[-1] == N
         rv_mod = rowvec.numel() // N
     frag_ok = nsplit and K % 64 == 0 and N % 32 == 0 and _WFRAG
+    if nsplit == 22 and not frag_ok:
+        nsplit = 0                            # f16x3 exists in fragment-order form only: fp32 MFMA
     if (pre_split or out_split) and not frag_ok:
         raise TocvpError("split activations need the fragment-order split GEMM (K, N % 32 == 0)")
     if out_split:
@@ -319,6 +338,11 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         out = torch.empty((M, nsplit, N), device=w.device, dtype=torch.bfloat16)
     elif out is None:
         out = torch.empty((M, N), device=w.device, dtype=torch.float32)
+    if frag_ok and nsplit == 22 and _CHECK_RANGE:
+        amax, wmax = float(x2.abs().max()), float(w.abs().max())
+        if amax >= F16X3_ACT_RANGE or wmax >= F16X3_WEIGHT_RANGE:
+            raise TocvpError(f"f16x3 operand out of range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}), "
+                             f"|w| max {wmax:.4g} (< {F16X3_WEIGHT_RANGE}); use precision='bf16x6'")
     if frag_ok:
         ws = _split_weight(w, nsplit, frag=True)
         _check(lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,

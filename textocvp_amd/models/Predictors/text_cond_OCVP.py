@@ -52,8 +52,9 @@ class BaseTextOCVP(nn.Module):
         self.pe = TemporalPositionalEncoding(d_model=self.token_dim,
                                              max_len=self.input_buffer_size + 1, mode="learned")
         self._text_cache = None
-        # arithmetic of the predictor GEMMs: "fp32" | "bf16x3" | "bf16x6" (kernels.gemm_precision)
-        self.gemm_precision = os.environ.get("TOCVP_PREDICTOR_PRECISION", "bf16x6")
+        # arithmetic of the predictor GEMMs: "fp32" | "bf16x3" | "bf16x6" | "f16x3" (kernels.gemm_precision)
+        # f16x3 = two fp16 planes per operand, 3 matrix-core products, fp32-class for |activation| < 255
+        self.gemm_precision = os.environ.get("TOCVP_PREDICTOR_PRECISION", "f16x3")
         self.last_layer_newest_frame_only = os.environ.get("TOCVP_LAST_LAYER_SUBSET", "1") != "0"
 
     def _instantiate_text_encoder(self):
