@@ -206,6 +206,22 @@ int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode, cons
                              const void* wfrag, const float* bias, float* y, int nimg, int H, int W,
                              int Cin, int Cout, int relu, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Same convolution with HYBRID f16 + fp8 split operands ("f16f8", conv_f16f8.hip): with X = 2^8 x,
+ * W = 2^10 w, Xh = f16(X), Wh = f16(W) the product is evaluated as Xh*Wh on the f16 matrix cores plus
+ * the two cross terms X*(W-Wh) + (X-Xh)*W on the fp8 (OCP e4m3, block-scaled 32x32x64) matrix cores
+ * at twice the f16 rate: 2/3 of the matrix cycles of bf16x3 for ~2.3x its (2^-16 class) error.
+ * Valid for |x| < 255 and |w| < 63 (operands saturate beyond).  in_mode / aux as tocvp_conv5x5_f32.
+ *   wf16 / wf8: fragment-order weight images written by tocvp_split_conv_weights_f16f8, of
+ *   tocvp_conv_weights_f16f8_bytes(0) / (1) bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_conv_weights_f16f8_bytes(int which);
+int tocvp_split_conv_weights_f16f8(const float* w, void* wf16, void* wf8, int Cout, int Cin,
+                                   void* stream);
+int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const void* wf16,
+                            const void* wf8, const float* bias, float* y, int nimg, int H, int W,
+                            int Cin, int Cout, int relu, void* stream);
+
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of
  *   w[co,ci,dy,dx];  w: (Cout,Cin,5,5), out: (25,Cout,Cin). */

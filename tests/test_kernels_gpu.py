@@ -383,3 +383,54 @@ def test_gemm_f16x3_range_behaviour(monkeypatch):
     with pytest.raises(k.TocvpError, match="out of range"):
         k.linear(x.to(DEV), w.to(DEV), precision="f16x3")
     k.linear(x[:3].contiguous().to(DEV), w.to(DEV), precision="f16x3")
+
+
+@pytest.mark.parametrize("n", [3, 37])
+def test_conv5x5_f16f8_accuracy(n):
+    """ hybrid f16 + fp8 conv: f16 main term + e4m3 cross terms -> ~1e-5 of the output scale """
+    k = _k()
+    x = rnd("bx", (n, 64, 64, 64))
+    x[0, :4, :4] = 0.0                                   # exact zeros, tiny and large activations
+    x[0, 5, 5, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 1e-3, 40.0, -90.0, 200.0, 0.25])
+    w = rnd("bw", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("bb", (64,), "uniform", 0.1)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2))
+    ref = ref.permute(0, 2, 3, 1)
+    wi = k.split_conv_weights_f16f8(w.to(DEV))
+    got = k.conv5x5_f16f8(x.to(DEV), wi, b.to(DEV), relu=True)
+    err = (got.cpu().double() - ref).abs()
+    scale = ref[1:].abs().max().item()
+    print(f"f16f8 conv: max abs err {err[1:].max().item():.3e} at scale {scale:.3g} "
+          f"(image with planted values: {err[0].max().item():.3e})")
+    assert err[1:].max().item() < 8e-5 * scale
+    assert err[0].max().item() < 8e-5 * max(scale, ref[0].abs().max().item())
+    # no ReLU: the sign structure must survive too
+    got_lin = k.conv5x5_f16f8(x.to(DEV), wi, b.to(DEV), relu=False)
+    ref_lin = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2).permute(0, 2, 3, 1)
+    assert (got_lin.cpu().double() - ref_lin).abs().max().item() < 8e-5 * ref_lin.abs().max().item()
+
+
+def test_conv5x5_f16f8_collapsed_input():
+    """ layer-1 mode of the hybrid conv: input = relu(cpos + S[border class]) built on the fly """
+    k = _k()
+    n, D, C0 = 6, 128, 64
+    slots = rnd("dslots", (n, D))
+    pw, pb = rnd("dpw", (D, 4, 1, 1)), rnd("dpb", (D,))
+    w0 = rnd("dw0", (C0, D, 5, 5), "uniform", (25 * D) ** -0.5)
+    b0 = rnd("db0", (C0,), "uniform", 0.1)
+    w1 = rnd("dw1", (64, C0, 5, 5), "uniform", (25 * C0) ** -0.5)
+    b1 = rnd("db1", (64,), "uniform", 0.1)
+    pos = O.soft_pos_embed(pw, pb, (64, 64))
+    x0 = (slots[:, None, None, :] + pos[None]).permute(0, 3, 1, 2)
+    a0 = torch.relu(F.conv2d(x0, w0, b0, padding=2))
+    ref = torch.relu(F.conv2d(a0.double(), w1.double(), b1.double(), padding=2)).permute(0, 2, 3, 1)
+    pos_d = k.pos_embed(pw.to(DEV), pb.to(DEV), 64, 64)
+    cpos = k.conv5x5(pos_d[None].contiguous(), k.pack_conv_weights(w0.to(DEV)), b0.to(DEV),
+                     relu=False)[0]
+    tapsum = k.dec_tapsum(w0.to(DEV))
+    S = k.linear(slots.to(DEV), tapsum.reshape(25 * C0, D)).reshape(n, 25, C0)
+    got = k.conv5x5_f16f8(None, k.split_conv_weights_f16f8(w1.to(DEV)), b1.to(DEV), relu=True,
+                          collapsed=(cpos.contiguous(), S.contiguous()))
+    err = (got.cpu().double() - ref).abs().max().item()
+    print(f"f16f8 collapsed conv: max abs err {err:.3e} at scale {ref.abs().max().item():.3g}")
+    assert err < 8e-5 * ref.abs().max().item()

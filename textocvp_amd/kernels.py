@@ -101,6 +101,13 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv_weights_f16f8_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "tocvp_split_conv_weights_f16f8": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv5x5_f16f8_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_metrics_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_psnr_ssim_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -626,6 +633,47 @@ def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=N
         _check(lib().tocvp_conv5x5_bf16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wsplit), _ptr(wfrag),
                                               _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
                                               int(bool(relu)), _stream()), "tocvp_conv5x5_bf16x3_f32")
+    if TIMER is not None:
+        TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
+    else:
+        run()
+    return out
+
+
+def split_conv_weights_f16f8(w):
+    """ (64, 64, 5, 5) fp32 -> (wf16, wf8) fragment-order weight images of the f16+fp8 hybrid conv """
+    Cout, Cin = w.shape[:2]
+    wf16 = torch.empty(lib().tocvp_conv_weights_f16f8_bytes(0), device=w.device, dtype=torch.uint8)
+    wf8 = torch.empty(lib().tocvp_conv_weights_f16f8_bytes(1), device=w.device, dtype=torch.uint8)
+    _check(lib().tocvp_split_conv_weights_f16f8(_ptr(w.contiguous()), _ptr(wf16), _ptr(wf8), Cout, Cin,
+                                                _stream()), "tocvp_split_conv_weights_f16f8")
+    return wf16, wf8
+
+
+def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None):
+    """
+    64->64 5x5 conv with hybrid f16 + fp8 split operands (tocvp_conv5x5_f16f8_f32), fp32 NHWC in/out.
+    wimgs = split_conv_weights_f16f8(weight); collapsed=(cpos, S): layer-1 mode (see conv5x5_bf16x3).
+    """
+    if collapsed is not None:
+        cpos, S = collapsed
+        H, W, Cin = cpos.shape
+        n = S.shape[0]
+        assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
+        xin, aux, mode, dev = cpos, S, 1, cpos.device
+    else:
+        n, H, W, Cin = x.shape
+        assert x.is_contiguous()
+        xin, aux, mode, dev = x, None, 0, x.device
+    wf16, wf8 = wimgs
+    Cout = bias.shape[0]
+    if out is None:
+        out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
+
+    def run():
+        _check(lib().tocvp_conv5x5_f16f8_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf16), _ptr(wf8),
+                                             _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
+                                             int(bool(relu)), _stream()), "tocvp_conv5x5_f16f8_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
     else:

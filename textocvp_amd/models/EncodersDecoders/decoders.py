@@ -80,6 +80,11 @@ class ConvDecoder(nn.Module):
         return self._derived.get(f"wf{i}", [conv.weight],
                                  lambda: K.split_conv_weights_frag_bf16(conv.weight))
 
+    def _hybrid(self, i):
+        conv = self.decoder[i].conv
+        return self._derived.get(f"wh{i}", [conv.weight],
+                                 lambda: K.split_conv_weights_f16f8(conv.weight))
+
     def _collapsed_layer0(self, pos_table):
         """ (cpos (H,W,C0), tapsum (25*C0, D)) for the current weights / position table """
         c0 = self.decoder[0].conv
@@ -121,9 +126,12 @@ class ConvDecoder(nn.Module):
                 if out is None or out.shape != (n, H, W, co):
                     out = torch.empty((n, H, W, co), device=dev, dtype=torch.float32)
                     bufs[which] = out
-                split = (self.conv_precision == "bf16x3" and conv.weight.shape[0] == 64
-                         and conv.weight.shape[1] == 64)
-                if split:
+                c64 = conv.weight.shape[0] == 64 and conv.weight.shape[1] == 64
+                split = self.conv_precision == "bf16x3" and c64
+                if self.conv_precision == "f16f8" and c64:
+                    x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
+                                        collapsed=(cpos, S) if i == 1 else None)
+                elif split:
                     x = K.conv5x5_bf16x3(x, self._split(i), conv.bias, relu=True, out=out,
                                          collapsed=(cpos, S) if i == 1 else None,
                                          wfrag=self._split_frag(i))
