@@ -37,6 +37,9 @@ PATH_GFLOP_PER_FRAME = 149.5             # reference algorithm, 
 
 ARITH = {
     ("fp32", "fp32"): "fp32",
+    ("f16f8", "f16x3"): "split operands on the matrix cores, fp32 accumulate / storage: decoder convs f16f8 "
+                        "(f16 hi product + two e4m3 cross products), predictor GEMMs f16x3 (hi/lo fp16 "
+                        "planes, 3 products); encoder, slot attention, softmax, LayerNorm fp32",
     ("bf16x3", "f16x3"): "split operands on the 16-bit matrix cores (decoder convs bf16x3 = hi/lo bf16 "
                          "planes, predictor GEMMs f16x3 = hi/lo fp16 planes; 3 products each), fp32 "
                          "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
@@ -196,21 +199,30 @@ def main():
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     rec = json.load(f)
-                if rec.get("slot_images_per_launch"):
+                # only a summary taken on the kernel that is running now counts
+                if rec.get("slot_images_per_launch") and \
+                        savi.decoder.conv_precision in rec.get("kernel", ""):
                     traffic = rec["hbm_bytes_per_launch"] * (
                         conv["units"] / conv["launches"]) / rec["slot_images_per_launch"]
-            split = savi.decoder.conv_precision == "bf16x3"
-            # split-bf16 executes 3 bf16 MFMA products per algorithmic product; `achieved` stays
-            # ALGORITHMIC flops / time, `peak` is the dense MFMA peak of the operand dtype
-            peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            # `achieved` is ALGORITHMIC flops / time; `peak` the dense MFMA peak of the 16-bit operand
+            # type the main products run on.  `matrix_units_per_product`: matrix-pipe time per
+            # algorithmic product in units of one 16-bit MFMA product (bf16x3: three bf16 products;
+            # f16f8: one f16 product + two e4m3 products at twice the f16 rate)
+            cp = savi.decoder.conv_precision
+            kernel_name, units, peak = {
+                "bf16x3": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 operands, 3 bf16 "
+                           "MFMA products per algorithmic product)", 3, BF16_MFMA_PEAK_TFLOPS),
+                "f16f8": ("conv5x5_f16f8_kernel (decoder 5x5 conv 64->64, hybrid split: f16 main product "
+                          "+ two e4m3 cross products on the 32x32x64 scaled MFMA)", 2,
+                          BF16_MFMA_PEAK_TFLOPS),
+            }.get(cp, ("conv5x5_mfma_kernel<64,64> (decoder 5x5 conv, exact fp32 MFMA)", 1,
+                       FP32_MFMA_PEAK_TFLOPS))
             roofline = {"bound": "mfma",
-                        "kernel": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 "
-                                   "operands, 3 MFMA products per algorithmic product)") if split
-                        else "conv5x5_mfma_kernel<64,64> (decoder 5x5 conv, exact fp32 MFMA)",
+                        "kernel": kernel_name,
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "mfma_products_per_flop": 3 if split else 1,
-                        "frac_executed_mfma": round((3 if split else 1) * achieved / peak, 4),
+                        "matrix_units_per_product": units,
+                        "frac_executed_mfma": round(units * achieved / peak, 4),
                         "traffic": traffic, "launches": conv["launches"],
                         "avg_launch_ms": round(avg_ms, 4),
                         "gflop_per_launch": round(gflop_per_launch, 2),
@@ -224,7 +236,7 @@ def main():
                 ex_tf = CONV_GFLOP_PER_SLOT_IMAGE * ex["units"] / ex["launches"] / ex_ms
                 roofline["exclusive"] = {"avg_launch_ms": round(ex_ms, 4), "achieved": round(ex_tf, 2),
                                          "frac": round(ex_tf / peak, 4),
-                                         "frac_executed_mfma": round((3 if split else 1) * ex_tf / peak, 4),
+                                         "frac_executed_mfma": round(units * ex_tf / peak, 4),
                                          "launches": ex["launches"]}
         line = {
             "metric": "predicted frames/sec (1 seed, 19 preds, 64x64, 30 slots)",

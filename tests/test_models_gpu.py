@@ -5,7 +5,7 @@ seeded inputs / weights.  Needs a real MI355X (pytest -m gpu).
 
 Tolerance = the north-star bar: 1e-4 absolute on slots, masks and rendered pixels, identical
 argmax_K(masks) maps (slot-index permutation).  Unit fixtures use 5e-5 where the arithmetic is
-fp32-class.  The suite runs in the default arithmetic (decoder convs bf16x3, predictor GEMMs
+fp32-class.  The suite runs in the default arithmetic (decoder convs f16f8, predictor GEMMs
 f16x3, everything else exact fp32 MFMA) and, with TOCVP_DECODER_PRECISION=fp32
 TOCVP_PREDICTOR_PRECISION=fp32, in the all-fp32 mode.
 """

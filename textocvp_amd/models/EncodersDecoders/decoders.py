@@ -61,9 +61,11 @@ class ConvDecoder(nn.Module):
         self.decoder = nn.Sequential(*mods)
         self._derived = Derived()
         self.max_slot_images = 2048          # slot images decoded per chunk (bounds HBM scratch)
-        # arithmetic of the 64->64 convs: "fp32" (exact fp32 MFMA) or "bf16x3" (split-bf16 operands
-        # on the bf16 matrix cores, ~2^-16 per-product error, 5.3x fewer matrix cycles)
-        self.conv_precision = os.environ.get("TOCVP_DECODER_PRECISION", "bf16x3")
+        # arithmetic of the 64->64 convs: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16 operands on
+        # the bf16 matrix cores, ~2^-16 per-product error, 5.3x fewer matrix cycles) or "f16f8"
+        # (f16 main product + two e4m3 cross products: 2/3 of the bf16x3 cycles, ~2.3x its error;
+        # needs W % 64 == 0, other shapes take the bf16x3 kernel)
+        self.conv_precision = os.environ.get("TOCVP_DECODER_PRECISION", "f16f8")
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
@@ -127,8 +129,8 @@ class ConvDecoder(nn.Module):
                     out = torch.empty((n, H, W, co), device=dev, dtype=torch.float32)
                     bufs[which] = out
                 c64 = conv.weight.shape[0] == 64 and conv.weight.shape[1] == 64
-                split = self.conv_precision == "bf16x3" and c64
-                if self.conv_precision == "f16f8" and c64:
+                split = self.conv_precision in ("bf16x3", "f16f8") and c64
+                if self.conv_precision == "f16f8" and c64 and W % 64 == 0 and H % 8 == 0:
                     x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
                                         collapsed=(cpos, S) if i == 1 else None)
                 elif split:
