@@ -227,9 +227,10 @@ def main():
                         "avg_launch_ms": round(avg_ms, 4),
                         "gflop_per_launch": round(gflop_per_launch, 2),
                         "share_of_step_time": round(conv["total_ms"] / 1e3 / elapsed, 3),
-                        "note": "achieved / avg_launch_ms are IN SITU: decoder launches run on a second "
-                                "stream concurrently with the rollout's kernels and share the CUs; "
-                                "'exclusive' is the same kernel with the GPU to itself"}
+                        "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the timed region); "
+                                "below 96 sequences per GPU the decoder runs on a second stream "
+                                "concurrently with the rollout and shares the CUs; 'exclusive' is the "
+                                "same kernel in one extra untimed pass with the GPU to itself"}
             ex = timer_excl.summary().get("conv5x5_64_64") if timer_excl else None
             if ex and ex["launches"]:
                 ex_ms = ex["total_ms"] / ex["launches"]

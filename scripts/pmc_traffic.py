@@ -8,12 +8,15 @@ cdna_hip_programming.md section 7:
     hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
   - both counters are in KiB;
   - on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced
-    streaming read -> doubled (the conv kernel stages its tiles with 16-byte loads);
+    streaming read -> doubled (the conv kernel stages its tiles with 16-byte loads).  Calibrated for
+    the f16f8 kernel's pattern (one 64-byte quarter of every 256-byte pixel per pass) with
+    scripts/probes/fetch_calib.hip: FETCH_SIZE = payload and the time of 2x the payload, i.e. whole
+    128-byte lines move and the x2 rule holds there too;
   - WRITE_SIZE is exact for 16-byte-per-lane streaming stores; the conv epilogue stores 4 B per
     lane in 128-byte segments, so the write side is an uncalibrated (but plausible) figure.
 
     python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> \
-           <kernel substring> <out.json>
+           <kernel substring> <out.json> [workgroups per slot image: 16 (8x32 tiles) | 8 (8x64 tiles)]
 """
 import csv
 import json
@@ -33,6 +36,7 @@ def per_kernel(path, counter, needle):
 
 def main():
     fpath, wpath, needle, out = sys.argv[1:5]
+    wg_per_image = float(sys.argv[5]) if len(sys.argv) > 5 else 16.0
     f, grid = per_kernel(fpath, "FETCH_SIZE", needle)
     w, _ = per_kernel(wpath, "WRITE_SIZE", needle)
     fetch_kib = sum(f) / len(f)
@@ -42,7 +46,7 @@ def main():
         "kernel": needle, "launches_fetch_pass": len(f), "launches_write_pass": len(w),
         "fetch_size_kib_mean_raw": fetch_kib, "write_size_kib_mean": write_kib,
         "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-        "workgroups_per_launch": workgroups, "slot_images_per_launch": workgroups / 16.0,
+        "workgroups_per_launch": workgroups, "slot_images_per_launch": workgroups / wg_per_image,
         "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts "
                       "1/2 of wide coalesced reads; KiB units)",
     }

@@ -154,6 +154,20 @@ def test_e2e_config2_against_reference_golden(k30):
 
 
 @torch.no_grad()
+@torch.no_grad()
+def test_decode_overlap_is_bit_identical(k7):
+    """ decoding on the second stream (the default below 96 sequences) runs the same kernels on the
+    same data as the serial order: every output must match bit for bit """
+    savi, pred = k7
+    videos = gpu(synth.synth_videos(2, 6, seed=3))
+    tokens, lengths = synth.synth_captions(2, max_len=10, seed=3)
+    noise = synth.synth_noise(2, 7, 128, seed=5)
+    outs = [forward_eval(savi, pred, videos, 2, 4, overlap_decode=ov, caption_tokens=gpu(tokens),
+                         caption_lengths=gpu(lengths), init_noise=noise) for ov in (False, True)]
+    for key in ("slot_history", "pred_slots", "pred_imgs", "masks"):
+        assert torch.equal(outs[0][key], outs[1][key]), key
+
+
 def test_e2e_against_oracle_fresh_inputs(k7):
     """ seeds not covered by the fixtures, B=3 with three different caption lengths """
     savi, pred = k7

@@ -36,7 +36,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     videos (B, L, C, H, W) in [0,1]; ``others`` carries caption_tokens / caption_lengths
     (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets, masks).
 
-    overlap_decode (default: env TOCVP_OVERLAP_DECODE, on): frame t is decoded on a SECOND HIP stream
+    overlap_decode (default: env TOCVP_OVERLAP_DECODE = auto|1|0; auto = on below 96 sequences): frame t is decoded on a SECOND HIP stream
     as soon as rollout step t is enqueued.  The rollout is a chain of short dependent kernels that
     cannot fill 256 CUs (especially while the window is short); the MFMA-bound decoder convolutions
     of already-predicted frames run in the gaps.  Same kernels, same arithmetic, same results.
@@ -49,7 +49,11 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
                              decode=False, **others)
     slot_history = out_model["slot_history"]
     if overlap_decode is None:
-        overlap_decode = os.environ.get("TOCVP_OVERLAP_DECODE", "1") != "0"
+        # "auto": only below ~96 sequences.  With more, the rollout's GEMMs fill the chip on their own
+        # and the overlap buys nothing (measured at B=128: 3924 vs 3927 frames/s) while every kernel's
+        # duration gets inflated by the sharing.
+        mode = os.environ.get("TOCVP_OVERLAP_DECODE", "auto")
+        overlap_decode = (B < 96) if mode == "auto" else mode != "0"
     if not (overlap_decode and slot_history.is_cuda):
         pred_slots = predictor(slot_history, **others)
         out_dec = decomp_model(mode="decode",
