@@ -106,7 +106,8 @@ int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const flo
  * ------------------------------------------------------------------------------------------- */
 int tocvp_layernorm_f32(const float* x, const float* add, int add_rows, const float* gamma,
                         const float* beta, float* y, int rows, int D, float eps, void* stream);
-/* same, output written as (rows, nsplit, D) bf16 planes (nsplit 2 or 3) for a split-bf16 GEMM */
+/* same, output written as operand planes of a split GEMM: nsplit 2 or 3 -> (rows, nsplit, D) bf16;
+ * nsplit 22 -> (rows, 2, D) fp16 planes of 2^8 y (the f16x3 arithmetic of tocvp_gemm_f16wfrag_f32) */
 int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows, const float* gamma,
                                const float* beta, void* ysplit, int nsplit, int rows, int D,
                                float eps, void* stream);
@@ -125,7 +126,8 @@ int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows, c
 int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                   float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                   const int32_t* key_len, void* stream);
-/* same, O written as (B*Tq, nsplit, H*dh) bf16 planes (nsplit 2 or 3) for a split-bf16 GEMM */
+/* same, O written as operand planes: (B*Tq, nsplit, H*dh) bf16 (nsplit 2 or 3) or, nsplit 22,
+ * (B*Tq, 2, H*dh) fp16 planes of 2^8 O */
 int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                          void* Osplit, int nsplit, int B, int H, int Tq, int Tk, int dh, float scale,
                          const int32_t* key_len, void* stream);

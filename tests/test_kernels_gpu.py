@@ -434,3 +434,46 @@ def test_conv5x5_f16f8_collapsed_input():
     err = (got.cpu().double() - ref).abs().max().item()
     print(f"f16f8 collapsed conv: max abs err {err:.3e} at scale {ref.abs().max().item():.3g}")
     assert err < 8e-5 * ref.abs().max().item()
+
+
+def test_f16_operand_planes_from_producers():
+    """ LayerNorm / attention / GEMM epilogues emitting fp16 operand planes (2^8 x, hi + lo) feed the
+    f16x3 GEMM directly: same result as splitting inside the GEMM """
+    k = _k()
+    M, D, Hd = 333, 512, 2048
+    x = rnd("px", (M, D))
+    g, b = 1 + rnd("pg", (D,), "uniform", 0.2), rnd("pb", (D,), "uniform", 0.1)
+    w1, b1 = rnd("pw1", (Hd, D), "uniform", D ** -0.5), rnd("pb1", (Hd,), "uniform", 0.1)
+    w2, b2 = rnd("pw2", (D, Hd), "uniform", Hd ** -0.5), rnd("pb2", (D,), "uniform", 0.1)
+    xd = x.to(DEV)
+    # reference chain in fp64
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6)
+    hid = torch.relu(ln @ w1.double().t() + b1.double())
+    ref = hid @ w2.double().t() + b2.double() + x.double()
+    with k.gemm_precision("f16x3"):
+        planes = k.layer_norm(xd, g.to(DEV), b.to(DEV), 1e-6, split=22)
+        assert isinstance(planes, k.SplitAct) and planes.planes.dtype == torch.float16
+        assert planes.nsplit == 22 and planes.planes.shape == (M, 2, D)
+        rebuilt = planes.planes.float().sum(dim=1) / 256.0
+        assert (rebuilt.cpu().double() - ln).abs().max().item() < 2e-6
+        h = k.linear(planes, w1.to(DEV), b1.to(DEV), act=k.ACT_RELU, out_split=22)
+        assert isinstance(h, k.SplitAct) and h.planes.shape == (M, 2, Hd)
+        got = k.linear(h, w2.to(DEV), b2.to(DEV), residual=xd)
+        # same chain with the split inside the GEMMs
+        y32 = k.layer_norm(xd, g.to(DEV), b.to(DEV), 1e-6)
+        got_in = k.linear(k.linear(y32, w1.to(DEV), b1.to(DEV), act=k.ACT_RELU), w2.to(DEV), b2.to(DEV),
+                          residual=xd)
+    err = (got.cpu().double() - ref).abs().max().item()
+    err_in = (got_in.cpu().double() - ref).abs().max().item()
+    print(f"f16 planes from producers: err {err:.2e} (split in the GEMM: {err_in:.2e})")
+    assert err < 2e-5 and err < 3 * err_in + 1e-6
+    # attention epilogue -> out-projection
+    B, T, E, H = 3, 70, 512, 8
+    qkv = rnd("pqkv", (B, T, 3 * E)).to(DEV)
+    wo = rnd("pwo", (E, E), "uniform", E ** -0.5).to(DEV)
+    with k.gemm_precision("f16x3"):
+        o32 = k.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, (E // H) ** -0.5)
+        osp = k.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, (E // H) ** -0.5, out_split=22)
+        assert (osp.planes.float().sum(dim=1).reshape(B, T, E) / 256.0 - o32).abs().max().item() < 2e-6
+        a, bb = k.linear(osp, wo), k.linear(o32, wo)
+    assert (a - bb).abs().max().item() < 1e-5

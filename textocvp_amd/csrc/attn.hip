@@ -160,17 +160,9 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
                 *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + c) = o;
             } else {
                 const int E = p.H * DH;
-                __bf16* ys = static_cast<__bf16*>(p.Osplit) +
-                             ((size_t)b * p.Tq + q) * p.nsplit * E + head * DH + c;
-                for (int sp = 0; sp < p.nsplit; ++sp) {
-                    bf16x4 piece;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        piece[u] = (__bf16)o[u];
-                        o[u] -= (float)piece[u];
-                    }
-                    *reinterpret_cast<bf16x4*>(ys + (size_t)sp * E) = piece;
-                }
+                const int planes = p.nsplit == 22 ? 2 : p.nsplit;
+                tocvp_store_planes4(p.Osplit, ((size_t)b * p.Tq + q) * planes * E + head * DH + c,
+                                    (size_t)E, o, p.nsplit);
             }
         }
     }
@@ -187,7 +179,7 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
     TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && (Osplit || ldo >= H * dh));
     TOCVP_CHECK_ARG(B <= 65535 && H <= 65535);
-    TOCVP_CHECK_ARG(Osplit == nullptr || nsplit == 2 || nsplit == 3);
+    TOCVP_CHECK_ARG(Osplit == nullptr || nsplit == 2 || nsplit == 3 || nsplit == 22);
     if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (O && (ldo & 3)) || !tocvp_aligned16(Q) ||
         !tocvp_aligned16(K) || !tocvp_aligned16(V) || (O && !tocvp_aligned16(O)) ||
         (Osplit && !tocvp_aligned16(Osplit)))

@@ -46,3 +46,43 @@ __device__ __forceinline__ float wave_sum64(float v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- split-plane activation stores (producer side of the split GEMMs) ---------------------------
+// nsplit 2 / 3: bf16 planes hi (+ mid) + lo of v;  nsplit 22: two fp16 planes of 2^8 v ("f16x3",
+// gemm_bf16.hip Elem<true>: the pre-scale keeps the lo plane out of the fp16 subnormals, values
+// saturate at |v| = 255.9).  Plane s of the 4 values goes to base + s * plane_stride (elements).
+constexpr float TOCVP_F16X3_ACT_SCALE = 256.f;
+constexpr float TOCVP_F16X3_WEIGHT_SCALE = 1024.f;
+
+__device__ __forceinline__ void tocvp_store_planes4(void* base, size_t elem_off, size_t plane_stride,
+                                                    f32x4 v, int nsplit) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    if (nsplit == 22) {
+        _Float16* ys = static_cast<_Float16*>(base) + elem_off;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = __builtin_amdgcn_fmed3f(v[u] * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            f16x4_t piece;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                piece[u] = (_Float16)v[u];
+                v[u] -= (float)piece[u];
+            }
+            *reinterpret_cast<f16x4_t*>(ys + (size_t)sp * plane_stride) = piece;
+        }
+    } else {
+        __bf16* ys = static_cast<__bf16*>(base) + elem_off;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            bf16x4_t piece;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                piece[u] = (__bf16)v[u];
+                v[u] -= (float)piece[u];
+            }
+            *reinterpret_cast<bf16x4_t*>(ys + (size_t)sp * plane_stride) = piece;
+        }
+    }
+}

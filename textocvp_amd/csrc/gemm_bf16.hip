@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
     // instead of 32 four-byte stores in 128-byte segments; the residual is read the same way.
     constexpr int SS = WN + 4;
     constexpr bool STAGE_FITS = (NW * 32 * SS * 4) <= (2 * BM * ROWB);
-    if (STAGE_FITS && !p.rowvec && !p.c_split) {
+    if (STAGE_FITS && !p.rowvec) {
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SS);
         constexpr int F4R = WN / 4;                                   // float4 per staged row
 #pragma unroll
@@ -432,7 +432,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                 if (row < p.M && col < p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
                     if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
-                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                    if (p.c_split)      // operand planes for the next split GEMM: (M, NS, N)
+                        tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, F16 ? 22 : NS);
+                    else
+                        *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                 v = apply_act(v, p.act);
                 if (p.R) v += p.R[(size_t)row * p.ldr + col];
                 if (p.c_split) {
+                    if (F16) v = __builtin_amdgcn_fmed3f(v * E::SA, -65504.f, 65504.f);
                     ET* cs = reinterpret_cast<ET*>(p.C) + (size_t)row * NS * p.N + col;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {

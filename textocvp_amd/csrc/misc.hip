@@ -10,7 +10,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// NSPLIT = 0: fp32 output y (rows, D); NSPLIT = 2/3: y is (rows, NSPLIT, D) bf16 planes
+// NSPLIT = 0: fp32 output y (rows, D); NSPLIT = 2/3: y is (rows, NSPLIT, D) bf16 planes;
+// NSPLIT = 22: y is (rows, 2, D) fp16 planes of 2^8 y (f16x3 GEMM operand)
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ add, int add_rows,
@@ -56,17 +57,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (NSPLIT == 0) {
                 *reinterpret_cast<f32x4*>(static_cast<float*>(yv) + (size_t)row * D + c) = o;
             } else {
-                __bf16* ys = static_cast<__bf16*>(yv) + (size_t)row * NSPLIT * D + c;
-#pragma unroll
-                for (int sp = 0; sp < (NSPLIT ? NSPLIT : 1); ++sp) {
-                    bf16x4 piece;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        piece[u] = (__bf16)o[u];
-                        o[u] -= (float)piece[u];
-                    }
-                    *reinterpret_cast<bf16x4*>(ys + (size_t)sp * D) = piece;
-                }
+                constexpr int PLANES = NSPLIT == 22 ? 2 : NSPLIT;
+                tocvp_store_planes4(yv, (size_t)row * PLANES * D + c, (size_t)D, o, NSPLIT);
             }
         }
     }
@@ -292,7 +284,7 @@ extern "C" int tocvp_layernorm_f32(const float* x, const float* add, int add_row
 extern "C" int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows,
                                           const float* gamma, const float* beta, void* ysplit,
                                           int nsplit, int rows, int D, float eps, void* stream) {
-    TOCVP_CHECK_ARG(x && gamma && beta && ysplit && (nsplit == 2 || nsplit == 3));
+    TOCVP_CHECK_ARG(x && gamma && beta && ysplit && (nsplit == 2 || nsplit == 3 || nsplit == 22));
     TOCVP_CHECK_ARG(rows >= 0 && D > 0 && D <= 1024 && (D & 3) == 0);
     TOCVP_CHECK_ARG(add == nullptr || add_rows > 0);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(ysplit) || !tocvp_aligned16(gamma) ||
@@ -300,7 +292,10 @@ extern "C" int tocvp_layernorm_split_bf16(const float* x, const float* add, int 
         return TOCVP_EALIGN;
     if (rows == 0) return TOCVP_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (nsplit == 2)
+    if (nsplit == 22)
+        hipLaunchKernelGGL(layernorm_kernel<22>, dim3(blocks_for(rows, 4)), dim3(256), 0, s, x, add,
+                           add_rows, gamma, beta, ysplit, rows, D, eps);
+    else if (nsplit == 2)
         hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks_for(rows, 4)), dim3(256), 0, s, x, add,
                            add_rows, gamma, beta, ysplit, rows, D, eps);
     else

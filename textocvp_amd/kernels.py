@@ -251,8 +251,9 @@ _CHECK_RANGE = os.environ.get("TOCVP_CHECK_RANGE", "0") != "0"
 
 class SplitAct:
     """
-    An activation already split into bf16 planes by its producer: ``planes`` is (rows, nsplit, D)
-    bf16, ``shape`` the logical fp32 shape (..., D).  Consumed as the A operand of a split GEMM.
+    An activation already split into operand planes by its producer: ``planes`` is (rows, P, D)
+    bf16 (P = 2 / 3) or fp16 (P = 2, values pre-scaled by 2^8), ``shape`` the logical fp32 shape
+    (..., D).  Consumed as the A operand of a split GEMM.
     """
 
     __slots__ = ("planes", "shape")
@@ -262,13 +263,20 @@ class SplitAct:
 
     @property
     def nsplit(self):
-        return self.planes.shape[1]
+        """ arithmetic code of the planes: 2 / 3 bf16 planes, 22 = two fp16 planes of 2^8 x (f16x3) """
+        return 22 if self.planes.dtype == torch.float16 else self.planes.shape[1]
+
+
+def _alloc_planes(rows, nsplit, D, device):
+    """ (rows, planes, D) operand planes for arithmetic code ``nsplit`` """
+    if nsplit == 22:
+        return torch.empty((rows, 2, D), device=device, dtype=torch.float16)
+    return torch.empty((rows, nsplit, D), device=device, dtype=torch.bfloat16)
 
 
 def active_nsplit():
     """ planes per operand of the GEMM arithmetic selected by the enclosing gemm_precision() """
-    ns = _NSPLIT.get(_GEMM_PRECISION, 0) if _WFRAG else 0
-    return ns if ns in (2, 3) else 0          # pre-split activations exist for the bf16 planes only
+    return _NSPLIT.get(_GEMM_PRECISION, 0) if _WFRAG else 0
 
 
 def _split_weight(w, nsplit, frag=False):
@@ -308,7 +316,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
     """
     y = act(x W^T + bias + rowvec[idx(row)]) + residual over the last axis of ``x``.
     x: (..., K) contiguous fp32 tensor or a SplitAct; weight: (N, K) in nn.Linear layout.
-    out_split = 2/3: return a SplitAct (bf16 planes) for a following split GEMM.
+    out_split = 2 / 3 / 22: return a SplitAct (operand planes) for a following split GEMM.
     """
     _dev_f32(weight, "weight")
     N, K = weight.shape
@@ -342,10 +350,10 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         raise TocvpError("split activations need the fragment-order split GEMM (K, N % 32 == 0)")
     if out_split:
         assert out is None and out_split == nsplit
-        out = torch.empty((M, nsplit, N), device=w.device, dtype=torch.bfloat16)
+        out = _alloc_planes(M, nsplit, N, w.device)
     elif out is None:
         out = torch.empty((M, N), device=w.device, dtype=torch.float32)
-    if frag_ok and nsplit == 22 and _CHECK_RANGE:
+    if frag_ok and nsplit == 22 and _CHECK_RANGE and not pre_split:
         amax, wmax = float(x2.abs().max()), float(w.abs().max())
         if amax >= F16X3_ACT_RANGE or wmax >= F16X3_WEIGHT_RANGE:
             raise TocvpError(f"f16x3 operand out of range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}), "
@@ -375,7 +383,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
 def layer_norm(x, gamma, beta, eps, add=None, split=0):
     """
     LayerNorm over the last axis; ``add`` (R, D) is added row-periodically before the norm.
-    split = 2/3: return a SplitAct (bf16 planes) instead of an fp32 tensor.
+    split = 2 / 3 / 22: return a SplitAct (operand planes) instead of an fp32 tensor.
     """
     _dev_f32(x, "x")
     D = x.shape[-1]
@@ -388,7 +396,7 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
         assert add.is_contiguous() and add.shape[-1] == D
         add_rows = add.numel() // D
     if split:
-        y = torch.empty((rows, split, D), device=x.device, dtype=torch.bfloat16)
+        y = _alloc_planes(rows, split, D, x.device)
         _check(lib().tocvp_layernorm_split_bf16(_ptr(x2), _ptr(add), add_rows, _ptr(gamma),
                                                 _ptr(beta), _ptr(y), int(split), rows, D, float(eps),
                                                 _stream()), "tocvp_layernorm_split_bf16")
@@ -421,7 +429,7 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
                                         _ptr(key_len), _ptr(bias), _stream()), "tocvp_mha_bias_f32")
         return o
     if out_split:
-        o = torch.empty((B * Tq, out_split, E), device=q.device, dtype=torch.bfloat16)
+        o = _alloc_planes(B * Tq, out_split, E, q.device)
         _check(lib().tocvp_mha_split_bf16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v),
                                           v.stride(1), _ptr(o), int(out_split), B, heads, Tq, Tk, dh,
                                           float(scale), _ptr(key_len), _stream()),
