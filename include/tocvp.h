@@ -220,9 +220,13 @@ int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode, cons
 size_t tocvp_conv_weights_f16f8_bytes(int which);
 int tocvp_split_conv_weights_f16f8(const float* w, void* wf16, void* wf8, int Cout, int Cin,
                                    void* stream);
+/* layout: bit 0 = x, bit 1 = y in the pass-major activation layout (n, 4, H, W, 16) (channel c of a
+ * pixel at plane c / 16) instead of NHWC.  The kernel consumes 16 channels per pass: NHWC makes every
+ * pass touch one 64-byte quarter of each pixel and whole 128-byte lines move twice; pass-major keeps
+ * the reads of a pass contiguous.  Private format between consecutive decoder layers. */
 int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const void* wf16,
                             const void* wf8, const float* bias, float* y, int nimg, int H, int W,
-                            int Cin, int Cout, int relu, void* stream);
+                            int Cin, int Cout, int relu, int layout, void* stream);
 
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of

@@ -3,6 +3,9 @@
 //         -o scripts/probes/conv_ablate_n scripts/probes/conv_ablate.hip
 #include "../../textocvp_amd/csrc/conv_f16f8.hip"
 #include <stdio.h>
+#ifndef LAYOUT
+#define LAYOUT 0
+#endif
 #include <vector>
 
 int main() {
@@ -21,13 +24,13 @@ int main() {
     hipMemset(b, 0, 256);
     tocvp_split_conv_weights_f16f8(w, wf16, wf8, 64, 64, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) tocvp_conv5x5_f16f8_f32(x, nullptr, 0, wf16, wf8, b, y, n, H, W, 64, 64, 1, nullptr);
+    for (int i = 0; i < 3; ++i) tocvp_conv5x5_f16f8_f32(x, nullptr, 0, wf16, wf8, b, y, n, H, W, 64, 64, 1, LAYOUT, nullptr);
     hipEventRecord(e0);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) tocvp_conv5x5_f16f8_f32(x, nullptr, 0, wf16, wf8, b, y, n, H, W, 64, 64, 1, nullptr);
+    for (int i = 0; i < reps; ++i) tocvp_conv5x5_f16f8_f32(x, nullptr, 0, wf16, wf8, b, y, n, H, W, 64, 64, 1, LAYOUT, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("ABLATE=%d: %.3f ms per launch (%d slot images) -> %.1f TFLOP/s algorithmic\n", TOCVP_ABLATE,
+    printf("LAYOUT=%d ABLATE=%d: %.3f ms per launch (%d slot images) -> %.1f TFLOP/s algorithmic\n", LAYOUT, TOCVP_ABLATE,
            ms / reps, n, n * 0.8388608 / (ms / reps));
     return 0;
 }

@@ -477,3 +477,24 @@ def test_f16_operand_planes_from_producers():
         assert (osp.planes.float().sum(dim=1).reshape(B, T, E) / 256.0 - o32).abs().max().item() < 2e-6
         a, bb = k.linear(osp, wo), k.linear(o32, wo)
     assert (a - bb).abs().max().item() < 1e-5
+
+
+def test_conv5x5_f16f8_pass_major_layout():
+    """ the private (n, 4, H, W, 16) layout between decoder layers holds exactly the NHWC values """
+    k = _k()
+    n = 5
+    x = rnd("bx", (n, 64, 64, 64))
+    w = rnd("bw", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("bb", (64,), "uniform", 0.1)
+    wi = k.split_conv_weights_f16f8(w.to(DEV))
+
+    def to_pm(t):
+        return t.view(n, 64, 64, 4, 16).permute(0, 3, 1, 2, 4).contiguous().view(n, 64, 64, 64)
+
+    ref = k.conv5x5_f16f8(x.to(DEV), wi, b.to(DEV), relu=True)
+    out_pm = k.conv5x5_f16f8(x.to(DEV), wi, b.to(DEV), relu=True, pm_out=True)
+    assert torch.equal(out_pm, to_pm(ref))
+    in_pm = k.conv5x5_f16f8(to_pm(x.to(DEV)), wi, b.to(DEV), relu=True, pm_in=True)
+    assert torch.equal(in_pm, ref)
+    both = k.conv5x5_f16f8(to_pm(x.to(DEV)), wi, b.to(DEV), relu=True, pm_in=True, pm_out=True)
+    assert torch.equal(both, to_pm(ref))

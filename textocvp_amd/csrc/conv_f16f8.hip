@@ -62,6 +62,7 @@ struct Args {
     const float* x; const float* aux; const unsigned char* wf16; const unsigned char* wf8;
     const float* bias; float* y;
     int nimg, H, W, relu;
+    int pm_in, pm_out;      // pass-major activation layout (n, 4, H, W, 16) instead of NHWC (n, H, W, 64)
 };
 
 __device__ __forceinline__ int border_class(int p, int n) {
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_f16f8_kernel(Args p) {
                 const int iy = min(max(ty0 + pix / IW - 2, 0), p.H - 1);
                 const int ix = min(max(tx0 + pix % IW - 2, 0), p.W - 1);
                 // uniform 64-bit base + 32-bit lane offset: half the address registers of per-lane pointers
-                const unsigned off = (unsigned)((iy * p.W + ix) * C + c) * 4u;
+                const unsigned off = p.pm_in
+                    ? (unsigned)(((pass * p.H + iy) * p.W + ix) * CCH + (c - pass * CCH)) * 4u
+                    : (unsigned)((iy * p.W + ix) * C + c) * 4u;
                 tv[it] = *reinterpret_cast<const f32x4*>(xbase + off);
                 if (MODE == 1) {
                     const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
@@ -282,13 +285,26 @@ __global__ __launch_bounds__(256, 2) void conv5x5_f16f8_kernel(Args p) {
                 }
         }
         __builtin_amdgcn_wave_barrier();
-        float* yrow = p.y + (((size_t)img * p.H + ty0 + 2 * wave + r2) * p.W + tx0) * C;
+        const int oy = ty0 + 2 * wave + r2;
+        if (p.pm_out) {
+            // plane-major: instruction `it` writes 16 pixels x 64 B of channel plane it >> 2 (1 KiB contiguous)
+            float* ybase = p.y + (size_t)img * p.H * p.W * C;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx = lane + 64 * it;
-            const int px = idx >> 4, c4 = (idx & 15) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
-            if (ABL != 6 || v[0] == 12345.f) *reinterpret_cast<f32x4*>(yrow + (size_t)px * C + c4) = v;
+            for (int it = 0; it < 16; ++it) {
+                const int plane = it >> 2, px = (it & 3) * 16 + (lane >> 2), cq = (lane & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
+                if (ABL != 6 || v[0] == 12345.f)
+                    *reinterpret_cast<f32x4*>(ybase + (((size_t)plane * p.H + oy) * p.W + tx0 + px) * CCH + cq) = v;
+            }
+        } else {
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = lane + 64 * it;
+                const int px = idx >> 4, c4 = (idx & 15) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
+                if (ABL != 6 || v[0] == 12345.f) *reinterpret_cast<f32x4*>(yrow + (size_t)px * C + c4) = v;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -343,7 +359,8 @@ extern "C" int tocvp_split_conv_weights_f16f8(const float* w, void* wf16, void* 
 
 extern "C" int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const void* wf16,
                                        const void* wf8, const float* bias, float* y, int nimg, int H,
-                                       int W, int Cin, int Cout, int relu, void* stream) {
+                                       int W, int Cin, int Cout, int relu, int layout, void* stream) {
+    TOCVP_CHECK_ARG(layout >= 0 && layout <= 3 && !(in_mode == 1 && (layout & 1)));
     TOCVP_CHECK_ARG(x && wf16 && wf8 && bias && y);
     TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
     TOCVP_CHECK_ARG(Cin == C && Cout == C);
@@ -354,7 +371,7 @@ extern "C" int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_
         return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     Args a{x, aux, static_cast<const unsigned char*>(wf16), static_cast<const unsigned char*>(wf8), bias,
-           y, nimg, H, W, relu};
+           y, nimg, H, W, relu, layout & 1, (layout >> 1) & 1};
     const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_mode == 0)

@@ -107,7 +107,7 @@ _SIGNATURES = {
     "tocvp_conv5x5_f16f8_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_metrics_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_psnr_ssim_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -658,10 +658,12 @@ def split_conv_weights_f16f8(w):
     return wf16, wf8
 
 
-def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None):
+def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False):
     """
-    64->64 5x5 conv with hybrid f16 + fp8 split operands (tocvp_conv5x5_f16f8_f32), fp32 NHWC in/out.
+    64->64 5x5 conv with hybrid f16 + fp8 split operands (tocvp_conv5x5_f16f8_f32), fp32 in/out.
     wimgs = split_conv_weights_f16f8(weight); collapsed=(cpos, S): layer-1 mode (see conv5x5_bf16x3).
+    x / out are (n, H, W, 64) NHWC; with pm_in / pm_out the same buffer holds the pass-major layout
+    (n, 4, H, W, 16) used between consecutive decoder layers (the tensor shape stays (n, H, W, 64)).
     """
     if collapsed is not None:
         cpos, S = collapsed
@@ -681,7 +683,8 @@ def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None):
     def run():
         _check(lib().tocvp_conv5x5_f16f8_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf16), _ptr(wf8),
                                              _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
-                                             int(bool(relu)), _stream()), "tocvp_conv5x5_f16f8_f32")
+                                             int(bool(relu)), int(bool(pm_in)) | (int(bool(pm_out)) << 1),
+                                             _stream()), "tocvp_conv5x5_f16f8_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
     else:

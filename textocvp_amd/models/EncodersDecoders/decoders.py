@@ -66,6 +66,7 @@ class ConvDecoder(nn.Module):
         # (f16 main product + two e4m3 cross products: 2/3 of the bf16x3 cycles, ~2.3x its error;
         # needs W % 64 == 0, other shapes take the bf16x3 kernel)
         self.conv_precision = os.environ.get("TOCVP_DECODER_PRECISION", "f16f8")
+        self.pass_major = os.environ.get("TOCVP_CONV_PASS_MAJOR", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
@@ -120,7 +121,7 @@ class ConvDecoder(nn.Module):
             f1 = min(F_, f0 + fpc)
             n = (f1 - f0) * Ks
             S = K.linear(slots[f0:f1].reshape(n, D), tapsum).reshape(n, 25, C0)
-            x, which = None, 0
+            x, which, pm_prev = None, 0, False
             for i in range(1, n_hidden):
                 conv = self.decoder[i].conv
                 co = conv.weight.shape[0]
@@ -131,8 +132,13 @@ class ConvDecoder(nn.Module):
                 c64 = conv.weight.shape[0] == 64 and conv.weight.shape[1] == 64
                 split = self.conv_precision in ("bf16x3", "f16f8") and c64
                 if self.conv_precision == "f16f8" and c64 and W % 64 == 0 and H % 8 == 0:
+                    # consecutive hybrid layers hand their activations over in the pass-major layout
+                    nxt = self.decoder[i + 1].conv if i + 1 < n_hidden else None
+                    pm_out = self.pass_major and nxt is not None and tuple(nxt.weight.shape[:2]) == (64, 64)
                     x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
-                                        collapsed=(cpos, S) if i == 1 else None)
+                                        collapsed=(cpos, S) if i == 1 else None,
+                                        pm_in=pm_prev, pm_out=pm_out)
+                    pm_prev = pm_out
                 elif split:
                     x = K.conv5x5_bf16x3(x, self._split(i), conv.bias, relu=True, out=out,
                                          collapsed=(cpos, S) if i == 1 else None,
