@@ -436,11 +436,13 @@ def test_conv5x5_f16f8_collapsed_input():
     assert err < 8e-5 * ref.abs().max().item()
 
 
-def test_f16_operand_planes_from_producers():
+@pytest.mark.parametrize("M", [333, 5003])
+def test_f16_operand_planes_from_producers(M):
     """ LayerNorm / attention / GEMM epilogues emitting fp16 operand planes (2^8 x, hi + lo) feed the
-    f16x3 GEMM directly: same result as splitting inside the GEMM """
+    f16x3 GEMM directly: same result as splitting inside the GEMM.  M = 5003 is large enough for the
+    256x128-tile DMA kernel (gemm_f16_planes_kernel), with a ragged last row block """
     k = _k()
-    M, D, Hd = 333, 512, 2048
+    D, Hd = 512, 2048
     x = rnd("px", (M, D))
     g, b = 1 + rnd("pg", (D,), "uniform", 0.2), rnd("pb", (D,), "uniform", 0.1)
     w1, b1 = rnd("pw1", (Hd, D), "uniform", D ** -0.5), rnd("pb1", (Hd,), "uniform", 0.1)

@@ -14,7 +14,14 @@
 
 #include "common.h"
 
+// timing experiments only (scripts/probes/gemm_ablate.hip): 1 = no weight-fragment loads in the k-loop,
+// 2 = no A loads, 3 = no A conversion / LDS stores, 4 = no MFMAs (and no LDS reads), 5 = no epilogue.
+#ifndef TOCVP_GEMM_ABLATE
+#define TOCVP_GEMM_ABLATE 0
+#endif
+
 namespace {
+constexpr int GABL = TOCVP_GEMM_ABLATE;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -389,19 +396,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         const int k1 = min(kt + 1, nk - 1), k2 = min(kt + 2, nk - 1);
-        gload_a(ra0, k1 * BK);
-        gload_b(b1, k1);
+        if (GABL != 2) gload_a(ra0, k1 * BK);
+        if (GABL != 1) gload_b(b1, k1);
         __builtin_amdgcn_sched_barrier(0);
-        compute(b0, 0);
-        lstore_a(ra0, 1);
+        if (GABL != 4) compute(b0, 0);
+        if (GABL != 3) lstore_a(ra0, 1);
         __syncthreads();
-        gload_a(ra0, k2 * BK);
-        gload_b(b0, k2);
+        if (GABL != 2) gload_a(ra0, k2 * BK);
+        if (GABL != 1) gload_b(b0, k2);
         __builtin_amdgcn_sched_barrier(0);
-        compute(b1, 1);
-        lstore_a(ra0, 0);
+        if (GABL != 4) compute(b1, 1);
+        if (GABL != 3) lstore_a(ra0, 0);
         __syncthreads();
     }
+    if (GABL == 5) return;
 
     // ---- fast epilogue (no row-vector, fp32 output): stage each 32-row block of the wave's tile in
     // LDS (the A images are dead after the loop's last barrier) and write it back as dwordx4 rows:
@@ -479,6 +487,160 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4 ("planes"): f16x3 GEMM whose A operand arrives as fp16 operand planes (M, 2, K) written by its
+//     producer (LayerNorm / attention / GEMM epilogue).  Measured on v3 (scripts/probes/gemm_ablate.hip,
+//     38400 x 2048 x 512): MFMA-only 142 us, everything-else-only 166 us, together 377 us -- the
+//     64 B/clk vector-memory path of the CU carries A (16 KB) + B (4 waves x 8 KB) per 128x128x32
+//     tile and is as busy as the matrix cores.  Here
+//       * a wave owns 128 x 64 of a 256 x 128 tile (4 x 2 accumulator tiles): a B fragment from
+//         L1/L2 feeds four row blocks -> 2/3 of the bytes per MFMA;
+//       * A planes go global -> LDS by DMA (global_load_lds, 16 B per lane): no staging registers
+//         (they pay for the 128 accumulator VGPRs) and no conversion instructions in the k-loop;
+//         the LDS image is lane-linear (8 lanes = one 128-byte row [plane 0 k0..31 | plane 1]), the
+//         bank-conflict-free order is obtained by permuting the 16-byte chunks on the SOURCE side:
+//         physical chunk c of row r holds logical chunk c ^ (r & 7);
+//       * two LDS stages, one barrier per k-tile, 2 workgroups / CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_f16_planes_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 128, BK = 32, MI = 4, NI = 2, NS = 2;
+    constexpr int STAGE = BM * 128;                                  // bytes per A stage
+    using E = Elem<true>;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = p.N / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const int KS = p.K / 16, nk = p.K / BK;
+
+    // ---- A: 8 DMA instructions per wave and k-tile, each 8 rows x 128 B = 1 KiB of LDS
+    const char* const a_bytes = reinterpret_cast<const char*>(p.A);
+    unsigned voff_a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);            // row of the tile
+        const int j = (lane & 7) ^ (row & 7);                        // logical chunk landing here
+        const int grow = min(m0 + row, p.M - 1);
+        voff_a[i] = (unsigned)((((size_t)grow * NS + (j >> 2)) * p.K + (j & 3) * 8) * 2);
+    }
+    auto dma_a = [&](int stage, int kt) {
+        const char* base = a_bytes + (size_t)kt * (BK * 2);          // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(base + voff_a[i]),
+                (__attribute__((address_space(3))) void*)(lds + stage * STAGE + (wave * 8 + i) * 1024),
+                16, 0, 0);
+    };
+
+    // ---- B fragments straight from L1/L2 (fragment order), one k-tile ahead in registers
+    const char* const w_bytes = reinterpret_cast<const char*>(p.W);
+    unsigned voff_b[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+        voff_b[j] = (unsigned)(((size_t)((n0 + wn * 64) / 32 + j) * KS * NS) * 64 + lane) * 16u;
+    auto gload_b = [&](f16x8 (&b)[2][NI][NS], int kt) {
+        const char* base = w_bytes + (size_t)kt * (2 * NS * 64 * 16);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    b[ks][j][s] = *reinterpret_cast<const f16x8*>(base + voff_b[j] + (ks * NS + s) * 64 * 16);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int x7 = (l31 & 7) << 4;                                   // lane's chunk permutation
+    auto compute = [&](const f16x8 (&b)[2][NI][NS], int stage) {
+        const unsigned char* a_base = lds + stage * STAGE + (wm * 128 + l31) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[MI][NS];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    a[i][s] = *reinterpret_cast<const f16x8*>(a_base + i * 32 * 128 +
+                                                              (((s * 4 + ks * 2 + h) << 4) ^ x7));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = E::mfma(a[i][0], b[ks][j][1], acc[i][j]);
+                    acc[i][j] = E::mfma(a[i][1], b[ks][j][0], acc[i][j]);
+                    acc[i][j] = E::mfma(a[i][0], b[ks][j][0], acc[i][j]);
+                }
+        }
+    };
+
+    f16x8 b0[2][NI][NS], b1[2][NI][NS];
+    dma_a(0, 0);
+    gload_b(b0, 0);
+    __builtin_amdgcn_s_waitcnt(0);                                   // vmcnt(0) lgkmcnt(0) expcnt(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {                             // nk even (host-checked)
+        const int k1 = min(kt + 1, nk - 1), k2 = min(kt + 2, nk - 1);
+        if (GABL != 2) dma_a(1, k1);
+        if (GABL != 1) gload_b(b1, k1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GABL != 4) compute(b0, 0);
+        __syncthreads();                                             // DMA of stage 1 landed, stage 0 free
+        if (GABL != 2) dma_a(0, k2);
+        if (GABL != 1) gload_b(b0, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GABL != 4) compute(b1, 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: 32-row blocks staged through LDS, written back as dwordx4 rows (see v3)
+    constexpr int SS = 64 + 4;
+    float* stage_f = reinterpret_cast<float*>(lds) + wave * (32 * SS);
+    constexpr int F4R = 64 / 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage_f[acc_row(r, h) * SS + j * 32 + l31] =
+                    apply_act(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bv, p.act);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < (32 * F4R) / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int rr = idx / F4R, c4 = (idx % F4R) * 4;
+            const int row = m0 + wm * 128 + i * 32 + rr, col = n0 + wn * 64 + c4;
+            if (row < p.M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + rr * SS + c4);
+                if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                if (p.c_split)
+                    tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, 22);
+                else
+                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // W (N, K) fp32 -> fragment-order bf16 planes Wf[nb][ks][plane][lane][8]
 template <bool F16>
 __global__ __launch_bounds__(256) void split_weights_frag_kernel(const float* __restrict__ w,
@@ -539,6 +701,16 @@ int launch_wfrag(const GemmArgs& p, hipStream_t s) {
 
 int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    static const bool planes_kernel = []() {
+        const char* e = getenv("TOCVP_GEMM_PLANES");
+        return !e || atoi(e) != 0;
+    }();
+    if (planes_kernel && p.a_split && !p.rowvec && (p.N % 128) == 0 && (p.K % 64) == 0 && big_tiles >= 512 &&
+        (size_t)p.M * 2 * p.K * 2 < 0xffffffffull) {
+        const int ntm = (p.M + 255) / 256, ntn = p.N / 128;
+        hipLaunchKernelGGL(gemm_f16_planes_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
+        return tocvp_launch_status();
+    }
     if (big_tiles < 192) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
     return launch_wfrag<2, 128, 128, 64, 64, 4, 2, true>(p, s);
 }

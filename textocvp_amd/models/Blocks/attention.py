@@ -20,9 +20,10 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 
 
 # TOCVP_PRESPLIT=1: activations that only feed GEMMs leave their producer (LayerNorm, attention and GEMM
-# epilogues) as operand planes, so the GEMM's k-loop loses its conversion instructions.  Measured: no
-# gain in the rollout (0.250 s vs 0.246 s at B=128; +3 % on an isolated 38400x2048x512 GEMM) - the GEMM
-# is bound by operand delivery and per-tile latency, not by its VALU work - so it stays off.
+# epilogues) as operand planes; with the f16x3 arithmetic (two fp16 planes = the bytes of the fp32 tensor)
+# the large GEMMs then run the DMA-fed 256x128 kernel (gemm_f16_planes_kernel).  Measured in the rollout at
+# B=128: 38400x2048x512 293 vs 301 us, 38400x512x2048 314 vs 301 us, 38400x512x512 118 vs 103 us, total
+# 250 vs 247 ms -> off by default (both forms are bound by L2->CU operand delivery).
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0")
 
 
@@ -38,7 +39,7 @@ def _ns(*dims):
     per column block of every consuming GEMM.
     """
     ns = K.active_nsplit()
-    if _PRESPLIT == "0" or (_PRESPLIT == "auto" and ns != 22):
+    if _PRESPLIT == "0":
         return 0
     return ns if ns and all(d % 64 == 0 for d in dims) else 0
 
