@@ -284,16 +284,22 @@ int tocvp_mha_bias_f32(const float* Q, int ldq, const float* K, int ldk, const f
  *    NULL = 1) and optional ReLU, NHWC fp32, fp32 MFMA.  upsample2 != 0: the input is the nearest x2
  *    upsampling of x ((nimg,H/2,W/2,Cin)), fused into the tile loader (model_blocks.py:23-45).
  *    wp: (9, Cout, Cin) from tocvp_pack_conv_weights_f32.  Cin % 64 == 0, Cout % 32 == 0, H % 8 == 0.
- *  tocvp_slot_composite_f32: decoded (B,K,N,F+1) -> recons (B,N,F) = sum_k feats*softmax_K(alpha),
- *    masks (B,K,N)   (decoders.py:279-283).  K <= 64.
+ *  tocvp_slot_composite_f32: decoded (B,K,N,ld) with features in [0,F) and alpha at F (ld >= F+1: the
+ *    producing GEMM may pad its width) -> recons (B,N,F) = sum_k feats*softmax_K(alpha), masks (B,K,N)
+ *    (decoders.py:279-283).  K <= 64.
  *  tocvp_bilinear_resize_f32: F.interpolate(bilinear, align_corners=False) (decoders.py:291-297);
  *    x: NHWC with channel stride `cstride` (first C channels used), y: NCHW (n,C,OH,OW).
  * ------------------------------------------------------------------------------------------- */
 int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
                       float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                       void* stream);
+/* same convolution with f16x3 split operands (fp32-class, |x| < 255, |w| < 63; Cin % 32 == 0): 3/16 of the
+ * matrix cycles of the fp32 MFMA form */
+int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
+                      float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
+                      void* stream);
 int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B, int K, int N,
-                             int F, void* stream);
+                             int F, int ld, void* stream);
 int tocvp_bilinear_resize_f32(const float* x, float* y, int n, int C, int cstride, int SH, int SW,
                               int OH, int OW, void* stream);
 

@@ -324,6 +324,14 @@ def test_conv3x3_scale_shift_upsample(Cin, Cout, S, up):
     wp = k.pack_conv_weights(w.to(DEV))
     got = k.conv3x3(x.to(DEV), wp, sc.to(DEV), sf.to(DEV), relu=True, upsample2=up)
     close(got, ref)
+    # split-fp16 form: fp32-class, compared with the fp64 result
+    ref64 = F.conv2d(xin.double(), w.double(), None, padding=1) * sc.double()[None, :, None, None] \
+        + sf.double()[None, :, None, None]
+    ref64 = torch.relu(ref64).permute(0, 2, 3, 1)
+    got16 = k.conv3x3(x.to(DEV), wp, sc.to(DEV), sf.to(DEV), relu=True, upsample2=up, precision="f16x3")
+    err16 = (got16.cpu().double() - ref64).abs().max().item()
+    err32 = (got.cpu().double() - ref64).abs().max().item()
+    assert err16 < max(3 * err32, 5e-6 * ref64.abs().max().item()), (err16, err32)
 
 
 def test_slot_composite_and_bilinear():
@@ -334,6 +342,10 @@ def test_slot_composite_and_bilinear():
     rec, masks = k.slot_composite(dec.to(DEV))
     close(rec, (feats * a).sum(1))
     close(masks, a[..., 0], tol=1e-6)
+    # padded rows (the producing GEMM rounds its width up to a multiple of 32): padding is ignored
+    padded = torch.cat([dec, torch.full((2, 24, 50, 31), 7.0)], dim=-1)
+    rec_p, masks_p = k.slot_composite(padded.to(DEV), feat_dim=96)
+    assert torch.equal(rec_p, rec) and torch.equal(masks_p, masks)
     x = rnd("bil", (2, 48, 48, 32))
     ref = F.interpolate(x[..., :3].permute(0, 3, 1, 2), size=(42, 42), mode="bilinear", align_corners=False)
     close(k.bilinear_resize_nhwc_to_nchw(x.to(DEV), 3, 42, 42), ref, tol=2e-6)

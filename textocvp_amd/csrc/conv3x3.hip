@@ -149,14 +149,169 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Args p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same convolution with f16x3 split operands (two fp16 planes of 2^8 x / 2^10 w, three
+// v_mfma_f32_32x32x16_f16 products per k-step, fp32-class; arithmetic of gemm_bf16.hip Elem<true>):
+// 3/16 of the matrix cycles of the fp32 MFMA form above.  32-channel chunks keep the (hi | lo) halo
+// image at 49 KB + 18 KB of weight slices -> two workgroups per CU.  Activations are split while the
+// halo tile is staged, the per-tap weight slice while it is copied into LDS.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+constexpr int CH = 32, ROWB = 2 * CH * 2 + 16;
+
+__device__ __forceinline__ void split4_f16(f32x4 v, float scale, unsigned char* dst) {
+    h16x4 hi, lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float X = __builtin_amdgcn_fmed3f(v[u] * scale, -65504.f, 65504.f);
+        hi[u] = (_Float16)X;
+        lo[u] = (_Float16)(X - (float)hi[u]);
+    }
+    *reinterpret_cast<h16x4*>(dst) = hi;
+    *reinterpret_cast<h16x4*>(dst + CH * 2) = lo;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
+    constexpr int COUTB = NB * 32;
+    constexpr int F4 = CH / 4;
+    constexpr int WREG = (COUTB * F4) / 256;
+    constexpr int NIT = (IH * IW * F4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IH * IW * ROWB + 2 * COUTB * ROWB];
+    unsigned char* in_s = lds;
+    unsigned char* w_s = lds + IH * IW * ROWB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles = tiles_x * (p.H / TH);
+    const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    const int co0 = blockIdx.y * COUTB;
+    const int SH = p.upsample ? p.H / 2 : p.H, SW = p.upsample ? p.W / 2 : p.W;
+    const int sh = p.upsample ? 1 : 0;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 wreg[WREG];
+    auto wload = [&](int tap, int ch) {
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = t + 256 * i;
+            const int co = idx / F4, c = (idx % F4) * 4;
+            wreg[i] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)tap * p.Cout + co0 + co) * p.Cin +
+                                                      ch * CH + c);
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = t + 256 * i;
+            const int co = idx / F4, c = (idx % F4) * 4;
+            split4_f16(wreg[i], TOCVP_F16X3_WEIGHT_SCALE, w_s + buf * COUTB * ROWB + co * ROWB + c * 2);
+        }
+    };
+
+    const int nch = p.Cin / CH;
+    for (int ch = 0; ch < nch; ++ch) {
+        f32x4 tv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(t + it * 256, IH * IW * F4 - 1);
+            const int pix = i / F4, c = (i % F4) * 4;
+            const int iy = min(max(ty0 + pix / IW - 1, 0), p.H - 1) >> sh;
+            const int ix = min(max(tx0 + pix % IW - 1, 0), p.W - 1) >> sh;
+            tv[it] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * SH + iy) * SW + ix) * p.Cin +
+                                                     ch * CH + c);
+        }
+        wload(0, ch);
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = t + it * 256;
+            if (i < IH * IW * F4) {
+                const int pix = i / F4, c = (i % F4) * 4;
+                const int iy = ty0 + pix / IW - 1, ix = tx0 + pix % IW - 1;
+                const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                f32x4 v = tv[it];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
+                split4_f16(v, TOCVP_F16X3_ACT_SCALE, in_s + pix * ROWB + c * 2);
+            }
+        }
+        wstore(0);
+        __syncthreads();
+
+        for (int tap = 0; tap < 9; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 9) wload(tap + 1, ch);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tap / 3, dx = tap % 3;
+            const unsigned char* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * ROWB + h * 16;
+            const unsigned char* b_base = w_s + buf * COUTB * ROWB + l31 * ROWB + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < CH / 16; ++ks) {
+                h16x8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[m] = *reinterpret_cast<const h16x8*>(a_base + m * IW * ROWB + ks * 32);
+                    al[m] = *reinterpret_cast<const h16x8*>(a_base + m * IW * ROWB + ks * 32 + CH * 2);
+                }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    bh[n] = *reinterpret_cast<const h16x8*>(b_base + n * 32 * ROWB + ks * 32);
+                    bl[n] = *reinterpret_cast<const h16x8*>(b_base + n * 32 * ROWB + ks * 32 + CH * 2);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    }
+            }
+            if (tap + 1 < 9) wstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    constexpr float UNSCALE = 1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_WEIGHT_SCALE);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int co = co0 + n * 32 + l31;
+        const float sc = (p.scale ? p.scale[co] : 1.f) * UNSCALE, sf = p.shift[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = ty0 + 2 * wave + m;
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W) * p.Cout + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = tx0 + acc_row(r, h);
+                if (ox < p.W) {
+                    float v = fmaf(acc[m][n][r], sc, sf);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    yrow[(size_t)ox * p.Cout] = v;
+                }
+            }
+        }
+    }
+}
+
 // decoded (B, K, N, F+1) -> recons (B, N, F), masks (B, K, N):  alpha = softmax_K(decoded[..., F])
 __global__ __launch_bounds__(256) void slot_composite_kernel(const float* __restrict__ dec,
                                                              float* __restrict__ recons,
                                                              float* __restrict__ masks, int K, int N,
-                                                             int F) {
+                                                             int F, int ld) {
     __shared__ float a_s[64];
     const int b = blockIdx.y, n = blockIdx.x, t = threadIdx.x;
-    const size_t row = (size_t)F + 1;
+    const size_t row = (size_t)ld;                                    // >= F + 1 (padded GEMM output)
     const float* base = dec + ((size_t)b * K * N + n) * row;          // slot k at + k*N*row
     if (t < 64) {
         float a = (t < K) ? base[(size_t)t * N * row + F] : -1.0e30f;
@@ -224,13 +379,35 @@ extern "C" int tocvp_conv3x3_f32(const float* x, const float* wp, const float* s
     return tocvp_launch_status();
 }
 
+extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale,
+                                       const float* shift, float* y, int nimg, int H, int W, int Cin,
+                                       int Cout, int relu, int upsample2, void* stream) {
+    TOCVP_CHECK_ARG(x && wp && shift && y);
+    TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0);
+    TOCVP_CHECK_ARG(Cin > 0 && (Cin % CH) == 0 && Cout > 0 && (Cout % 32) == 0);
+    TOCVP_CHECK_ARG(!upsample2 || ((H % 2) == 0 && (W % 2) == 0));
+    const size_t tiles = (size_t)((W + TW - 1) / TW) * (H / TH);
+    TOCVP_CHECK_ARG(nimg * tiles < 0x7fffffffu && Cout / 32 <= 65535);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(wp)) return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    Conv3Args a{x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2 ? 1 : 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout % 64 == 0)
+        hipLaunchKernelGGL(conv3x3_f16x3_kernel<2>, dim3((unsigned)(nimg * tiles), Cout / 64), dim3(256),
+                           0, s, a);
+    else
+        hipLaunchKernelGGL(conv3x3_f16x3_kernel<1>, dim3((unsigned)(nimg * tiles), Cout / 32), dim3(256),
+                           0, s, a);
+    return tocvp_launch_status();
+}
+
 extern "C" int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B,
-                                        int K, int N, int F, void* stream) {
+                                        int K, int N, int F, int ld, void* stream) {
     TOCVP_CHECK_ARG(decoded && recons && masks);
-    TOCVP_CHECK_ARG(B >= 0 && B <= 65535 && K > 0 && K <= 64 && N > 0 && F > 0);
+    TOCVP_CHECK_ARG(B >= 0 && B <= 65535 && K > 0 && K <= 64 && N > 0 && F > 0 && ld >= F + 1);
     if (B == 0) return TOCVP_OK;
     hipLaunchKernelGGL(slot_composite_kernel, dim3(N, B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), decoded, recons, masks, K, N, F);
+                       static_cast<hipStream_t>(stream), decoded, recons, masks, K, N, F, ld);
     return tocvp_launch_status();
 }
 

@@ -117,9 +117,13 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv3x3_f16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
     "tocvp_slot_composite_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_int, ctypes.c_void_p]),
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_bilinear_resize_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -707,30 +711,35 @@ def psnr_ssim(preds, targets, clamp01=True, want_psnr=True, want_ssim=True):
     return psnr, ssim
 
 
-def conv3x3(x, wp, scale, shift, relu=True, upsample2=False):
+def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
     """
     NHWC (n, SH, SW, Cin) -> (n, H, W, Cout): 3x3 conv (pad 1) + per-channel scale/shift (+ReLU) on
     the (optionally nearest-x2-upsampled) input; wp packed (9, Cout, Cin).
+    precision: "fp32" (exact fp32 MFMA) or "f16x3" (split fp16 operands, fp32-class, |x| < 255).
     """
     n, SH, SW, Cin = x.shape
     H, W = (2 * SH, 2 * SW) if upsample2 else (SH, SW)
     Cout = wp.shape[1]
     assert x.is_contiguous() and wp.shape[0] == 9 and wp.shape[2] == Cin
     y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
-    _check(lib().tocvp_conv3x3_f32(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin,
-                                   Cout, int(bool(relu)), int(bool(upsample2)), _stream()),
-           "tocvp_conv3x3_f32")
+    fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
+    _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
+              int(bool(upsample2)), _stream()), "tocvp_conv3x3_" + precision)
     return y
 
 
-def slot_composite(decoded):
-    """ decoded (B, K, N, F+1) -> recons (B, N, F), masks (B, K, N) """
-    B, Ks, N, F1 = decoded.shape
+def slot_composite(decoded, feat_dim=None):
+    """
+    decoded (B, K, N, ld) -> recons (B, N, F), masks (B, K, N); features in [..., :F], alpha at
+    [..., F], F = feat_dim (default ld - 1; ld > F + 1 when the producing GEMM padded its width).
+    """
+    B, Ks, N, ld = decoded.shape
+    F_ = ld - 1 if feat_dim is None else int(feat_dim)
     _dev_f32(decoded, "decoded")
     decoded = decoded.contiguous()
-    recons = torch.empty((B, N, F1 - 1), device=decoded.device, dtype=torch.float32)
+    recons = torch.empty((B, N, F_), device=decoded.device, dtype=torch.float32)
     masks = torch.empty((B, Ks, N), device=decoded.device, dtype=torch.float32)
-    _check(lib().tocvp_slot_composite_f32(_ptr(decoded), _ptr(recons), _ptr(masks), B, Ks, N, F1 - 1,
+    _check(lib().tocvp_slot_composite_f32(_ptr(decoded), _ptr(recons), _ptr(masks), B, Ks, N, F_, ld,
                                           _stream()), "tocvp_slot_composite_f32")
     return recons, masks
 
