@@ -298,6 +298,11 @@ int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale, const
 int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
                       float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                       void* stream);
+/* generic 5x5 convolution (pad 2, + bias, optional ReLU; Cin % 32 == 0, Cout % 32 == 0, H % 8 == 0) with
+ * the same f16x3 split operands: SAVi encoder convs 32 -> 32 (encoders.py:99-159).  wp: (25, Cout, Cin)
+ * from tocvp_pack_conv_weights_f32. */
+int tocvp_conv5x5_f16x3_f32(const float* x, const float* wp, const float* bias, float* y, int nimg,
+                            int H, int W, int Cin, int Cout, int relu, void* stream);
 int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B, int K, int N,
                              int F, int ld, void* stream);
 int tocvp_bilinear_resize_f32(const float* x, float* y, int n, int C, int cstride, int SH, int SW,

@@ -512,3 +512,19 @@ def test_conv5x5_f16f8_pass_major_layout():
     assert torch.equal(in_pm, ref)
     both = k.conv5x5_f16f8(to_pm(x.to(DEV)), wi, b.to(DEV), relu=True, pm_in=True, pm_out=True)
     assert torch.equal(both, to_pm(ref))
+
+
+@pytest.mark.parametrize("Cin,Cout,n", [(32, 32, 5), (64, 64, 2)])
+def test_conv5x5_f16x3_generic(Cin, Cout, n):
+    """ generic split-fp16 5x5 conv (SAVi encoder shapes): fp32-class against the fp64 result """
+    k = _k()
+    x = rnd("gx", (n, 64, 64, Cin))
+    w = rnd("gw", (Cout, Cin, 5, 5), "uniform", (25 * Cin) ** -0.5)
+    b = rnd("gb", (Cout,), "uniform", 0.1)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2)).permute(0, 2, 3, 1)
+    wp = k.pack_conv_weights(w.to(DEV))
+    got = k.conv5x5(x.to(DEV), wp, b.to(DEV), relu=True, precision="f16x3")
+    got32 = k.conv5x5(x.to(DEV), wp, b.to(DEV), relu=True)
+    err, err32 = (got.cpu().double() - ref).abs().max().item(), (got32.cpu().double() - ref).abs().max().item()
+    print(f"conv5x5 f16x3 {Cin}->{Cout}: err {err:.2e} (fp32 mfma {err32:.2e})")
+    assert err < max(3 * err32, 5e-6 * ref.abs().max().item())

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;
+constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;    // IH / IW: 3x3 fp32 kernel (split kernel: per KS)
 constexpr int CC = 64, CS = CC + 4;
 
 struct Conv3Args {
@@ -172,8 +172,11 @@ __device__ __forceinline__ void split4_f16(f32x4 v, float scale, unsigned char* 
     *reinterpret_cast<h16x4*>(dst + CH * 2) = lo;
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
+// KS = 3 (image head of the DINOSAUR decoder) or 5 (SAVi encoder convs 32 -> 32, decoder shapes that the
+// dedicated 64 -> 64 kernels do not take); halo KS / 2, same 8 x 32 pixel tile.
+template <int NB, int KS>
+__global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
+    constexpr int HALO = KS / 2, IH = TH + KS - 1, IW = TW + KS - 1, NTAP = KS * KS;
     constexpr int COUTB = NB * 32;
     constexpr int F4 = CH / 4;
     constexpr int WREG = (COUTB * F4) / 256;
@@ -225,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
         for (int it = 0; it < NIT; ++it) {
             const int i = min(t + it * 256, IH * IW * F4 - 1);
             const int pix = i / F4, c = (i % F4) * 4;
-            const int iy = min(max(ty0 + pix / IW - 1, 0), p.H - 1) >> sh;
-            const int ix = min(max(tx0 + pix % IW - 1, 0), p.W - 1) >> sh;
+            const int iy = min(max(ty0 + pix / IW - HALO, 0), p.H - 1) >> sh;
+            const int ix = min(max(tx0 + pix % IW - HALO, 0), p.W - 1) >> sh;
             tv[it] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * SH + iy) * SW + ix) * p.Cin +
                                                      ch * CH + c);
         }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
             const int i = t + it * 256;
             if (i < IH * IW * F4) {
                 const int pix = i / F4, c = (i % F4) * 4;
-                const int iy = ty0 + pix / IW - 1, ix = tx0 + pix % IW - 1;
+                const int iy = ty0 + pix / IW - HALO, ix = tx0 + pix % IW - HALO;
                 const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 f32x4 v = tv[it];
 #pragma unroll
@@ -248,11 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
         wstore(0);
         __syncthreads();
 
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NTAP; ++tap) {
             const int buf = tap & 1;
-            if (tap + 1 < 9) wload(tap + 1, ch);
+            if (tap + 1 < NTAP) wload(tap + 1, ch);
             __builtin_amdgcn_sched_barrier(0);
-            const int dy = tap / 3, dx = tap % 3;
+            const int dy = tap / KS, dx = tap % KS;
             const unsigned char* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * ROWB + h * 16;
             const unsigned char* b_base = w_s + buf * COUTB * ROWB + l31 * ROWB + h * 16;
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(Conv3Args p) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
                     }
             }
-            if (tap + 1 < 9) wstore(buf ^ 1);
+            if (tap + 1 < NTAP) wstore(buf ^ 1);
             __syncthreads();
         }
     }
@@ -379,10 +382,11 @@ extern "C" int tocvp_conv3x3_f32(const float* x, const float* wp, const float* s
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale,
-                                       const float* shift, float* y, int nimg, int H, int W, int Cin,
-                                       int Cout, int relu, int upsample2, void* stream) {
+static int launch_convk_f16x3(const float* x, const float* wp, const float* scale, const float* shift,
+                              float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
+                              int ksize, void* stream) {
     TOCVP_CHECK_ARG(x && wp && shift && y);
+    TOCVP_CHECK_ARG(ksize == 3 || ksize == 5);
     TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0);
     TOCVP_CHECK_ARG(Cin > 0 && (Cin % CH) == 0 && Cout > 0 && (Cout % 32) == 0);
     TOCVP_CHECK_ARG(!upsample2 || ((H % 2) == 0 && (W % 2) == 0));
@@ -392,13 +396,27 @@ extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const fl
     if (nimg == 0) return TOCVP_OK;
     Conv3Args a{x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2 ? 1 : 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (Cout % 64 == 0)
-        hipLaunchKernelGGL(conv3x3_f16x3_kernel<2>, dim3((unsigned)(nimg * tiles), Cout / 64), dim3(256),
-                           0, s, a);
-    else
-        hipLaunchKernelGGL(conv3x3_f16x3_kernel<1>, dim3((unsigned)(nimg * tiles), Cout / 32), dim3(256),
-                           0, s, a);
+    const dim3 g64((unsigned)(nimg * tiles), Cout / 64), g32((unsigned)(nimg * tiles), Cout / 32);
+    if (ksize == 3) {
+        if (Cout % 64 == 0) hipLaunchKernelGGL((convk_f16x3_kernel<2, 3>), g64, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((convk_f16x3_kernel<1, 3>), g32, dim3(256), 0, s, a);
+    } else {
+        if (Cout % 64 == 0) hipLaunchKernelGGL((convk_f16x3_kernel<2, 5>), g64, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((convk_f16x3_kernel<1, 5>), g32, dim3(256), 0, s, a);
+    }
     return tocvp_launch_status();
+}
+
+extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale,
+                                       const float* shift, float* y, int nimg, int H, int W, int Cin,
+                                       int Cout, int relu, int upsample2, void* stream) {
+    return launch_convk_f16x3(x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2, 3, stream);
+}
+
+extern "C" int tocvp_conv5x5_f16x3_f32(const float* x, const float* wp, const float* bias, float* y,
+                                       int nimg, int H, int W, int Cin, int Cout, int relu,
+                                       void* stream) {
+    return launch_convk_f16x3(x, wp, nullptr, bias, y, nimg, H, W, Cin, Cout, relu, 0, 5, stream);
 }
 
 extern "C" int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B,

@@ -121,6 +121,9 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv5x5_f16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_slot_composite_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -505,14 +508,23 @@ def conv5x5_in3(x, w, bias):
     return y
 
 
-def conv5x5(x, wp, bias, relu=True, out=None):
-    """ NHWC (n, H, W, Cin) -> (n, H, W, Cout) with packed weights (25, Cout, Cin). """
+def conv5x5(x, wp, bias, relu=True, out=None, precision="fp32"):
+    """
+    NHWC (n, H, W, Cin) -> (n, H, W, Cout) with packed weights (25, Cout, Cin).
+    precision "f16x3": split fp16 operands (fp32-class, |x| < 255; Cin, Cout % 32 == 0), else fp32 MFMA.
+    """
     n, H, W, Cin = x.shape
     Cout = wp.shape[1]
     assert x.is_contiguous() and wp.shape[0] == 25 and wp.shape[2] == Cin
     if out is None:
         out = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
+    split = precision == "f16x3" and Cin % 32 == 0 and Cout % 32 == 0 and H % 8 == 0
     def run():
+        if split:
+            _check(lib().tocvp_conv5x5_f16x3_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
+                                                 Cout, int(bool(relu)), _stream()),
+                   "tocvp_conv5x5_f16x3_f32")
+            return
         _check(lib().tocvp_conv5x5_f32(_ptr(x), None, 0, _ptr(wp), _ptr(bias), _ptr(out), n, H, W,
                                        Cin, Cout, int(bool(relu)), _stream()), "tocvp_conv5x5_f32")
     if TIMER is not None:

@@ -3,6 +3,8 @@ Image encoders.  Reference: models/EncodersDecoders/encoders.py (get_encoder :27
 SimpleConvEncoder :99-159).  Only the conv encoder of the SAVi configs is on the hot path.
 """
 
+import os
+
 import torch.nn as nn
 
 from ... import kernels as K
@@ -43,6 +45,8 @@ class SimpleConvEncoder(nn.Module):
             c = h
         self.encoder = nn.Sequential(*blocks)
         self._derived = Derived()
+        # convs 1..: "f16x3" (split fp16 operands on the f16 matrix cores, fp32-class) or "fp32" (exact MFMA)
+        self.conv_precision = os.environ.get("TOCVP_ENCODER_PRECISION", "f16x3")
 
     def forward_nhwc(self, x):
         """ x: (n, 3, H, W) view of contiguous image planes -> (n, H, W, C) """
@@ -51,7 +55,7 @@ class SimpleConvEncoder(nn.Module):
         for i in range(1, len(self.encoder)):
             conv = self.encoder[i].conv
             wp = self._derived.get(f"wp{i}", [conv.weight], lambda c=conv: K.pack_conv_weights(c.weight))
-            y = K.conv5x5(y, wp, conv.bias, relu=True)
+            y = K.conv5x5(y, wp, conv.bias, relu=True, precision=self.conv_precision)
         return y
 
     def forward(self, x):
