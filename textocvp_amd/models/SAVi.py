@@ -5,6 +5,7 @@ decode :241-261, broadcast :264-275, _init_model :278-293).
 """
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -42,6 +43,8 @@ class SAVi(nn.Module):
         self.slot_dim = slot_dim
         self.in_channels = in_channels
         self.mlp_encoder_dim = mlp_encoder_dim
+        # arithmetic of the per-pixel encoder MLP and k/v projection GEMMs (shapes that fit the split kernel)
+        self.encoder_gemm_precision = os.environ.get("TOCVP_ENCODER_GEMM_PRECISION", "f16x3")
 
         self.initializer = get_initializer(mode=initializer, slot_dim=slot_dim, num_slots=num_slots)
         self.transition_module = get_transition_module(slot_dim=slot_dim, **transition_module)
@@ -129,12 +132,15 @@ class SAVi(nn.Module):
         ln, l1, l2 = self.encoder_mlp[0], self.encoder_mlp[1], self.encoder_mlp[3]
         z = K.layer_norm(y.reshape(n * H * W, C), ln.weight, ln.bias, ln.eps,
                          add=self.encoder_pos_embedding.table().reshape(H * W, C))
-        z = K.linear(K.linear(z, l1.weight, l1.bias, act=K.ACT_RELU), l2.weight, l2.bias)
+        with K.gemm_precision(self.encoder_gemm_precision):
+            z = K.linear(K.linear(z, l1.weight, l1.bias, act=K.ACT_RELU), l2.weight, l2.bias)
         return z.reshape(n, H * W, self.mlp_encoder_dim)
 
     def _encode_kv(self, imgs):
         """ image batch -> fused slot-attention keys/values (n, N, 2D) """
-        return self.slot_attention.project_kv(self._encode_feats(imgs))
+        feats = self._encode_feats(imgs)
+        with K.gemm_precision(self.encoder_gemm_precision):
+            return self.slot_attention.project_kv(feats)
 
     def encode(self, x):
         """ x (B, C, H, W) -> features (B, N, mlp_encoder_dim)   (SAVi.py:226-238) """
