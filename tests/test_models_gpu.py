@@ -155,6 +155,23 @@ def test_e2e_config2_against_reference_golden(k30):
 
 @torch.no_grad()
 @torch.no_grad()
+def test_fp16_plane_range_check(k7, monkeypatch):
+    """ TOCVP_CHECK_RANGE: every fp16-plane kernel on the path sees operands inside |x| < 255 on the
+    synthetic model, and an out-of-range activation is reported instead of saturating silently """
+    from textocvp_amd import kernels as K
+    monkeypatch.setattr(K, "_CHECK_RANGE", True)
+    savi, pred = k7
+    videos = gpu(synth.synth_videos(2, 5, seed=0))
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    forward_eval(savi, pred, videos, 1, 4, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                 init_noise=synth.synth_noise(2, 7, 128, seed=1))
+    w = synth.synth_tensor("rc.w", (64, 64, 5, 5), "uniform", 0.02).to(DEV)
+    x = torch.full((1, 64, 64, 64), 300.0, device=DEV)
+    with pytest.raises(K.TocvpError, match="out of the fp16-plane range"):
+        K.conv5x5_f16f8(x, K.split_conv_weights_f16f8(w), torch.zeros(64, device=DEV))
+
+
+@torch.no_grad()
 def test_decode_overlap_is_bit_identical(k7):
     """ decoding on the second stream (the default below 96 sequences) runs the same kernels on the
     same data as the serial order: every output must match bit for bit """

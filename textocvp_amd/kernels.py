@@ -256,6 +256,13 @@ F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
 _CHECK_RANGE = os.environ.get("TOCVP_CHECK_RANGE", "0") != "0"
 
 
+def _check_f16_range(amax, what):
+    """ TOCVP_CHECK_RANGE=1: the fp16-plane arithmetic saturates silently at |x| = 255.9 """
+    if amax >= F16X3_ACT_RANGE:
+        raise TocvpError(f"{what} out of the fp16-plane range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}); "
+                         f"select the bf16 / fp32 arithmetic for this model")
+
+
 class SplitAct:
     """
     An activation already split into operand planes by its producer: ``planes`` is (rows, P, D)
@@ -519,6 +526,8 @@ def conv5x5(x, wp, bias, relu=True, out=None, precision="fp32"):
     if out is None:
         out = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
     split = precision == "f16x3" and Cin % 32 == 0 and Cout % 32 == 0 and H % 8 == 0
+    if split and _CHECK_RANGE:
+        _check_f16_range(float(x.abs().max()), "conv5x5 (f16x3) input")
     def run():
         if split:
             _check(lib().tocvp_conv5x5_f16x3_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
@@ -693,6 +702,8 @@ def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None, pm_in=Fal
         xin, aux, mode, dev = x, None, 0, x.device
     wf16, wf8 = wimgs
     Cout = bias.shape[0]
+    if _CHECK_RANGE and mode == 0:
+        _check_f16_range(float(xin.abs().max()), "conv5x5_f16f8 input")
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
 
@@ -734,6 +745,8 @@ def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
     Cout = wp.shape[1]
     assert x.is_contiguous() and wp.shape[0] == 9 and wp.shape[2] == Cin
     y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
+    if precision == "f16x3" and _CHECK_RANGE:
+        _check_f16_range(float(x.abs().max()), "conv3x3 (f16x3) input")
     fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
     _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
               int(bool(upsample2)), _stream()), "tocvp_conv3x3_" + precision)
