@@ -172,6 +172,34 @@ def test_fp16_plane_range_check(k7, monkeypatch):
 
 
 @torch.no_grad()
+def test_calibrate_precision_moves_out_of_range_modules():
+    """ a checkpoint whose decoder activations leave the fp16-plane range is moved to the range-free
+    arithmetic by the calibration pass, and the result is then finite and close to the fp32 path """
+    from textocvp_amd.setup_model import calibrate_precision
+    savi, pred = build(7, 4)
+    with torch.no_grad():
+        savi.decoder.decoder[1].conv.weight.mul_(40.0)          # layer-1 activations far above 255
+    videos = gpu(synth.synth_videos(2, 5, seed=0))
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    kw = dict(caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+              init_noise=synth.synth_noise(2, 7, 128, seed=1))
+    saturated = forward_eval(savi, pred, videos, 1, 4, **kw)       # f16f8 planes pinned at 255.9
+    changed = calibrate_precision(savi, pred, videos, 1, 4, **kw)
+    assert changed == {("ConvDecoder", "conv_precision"): "bf16x3"}
+    out = forward_eval(savi, pred, videos, 1, 4, **kw)
+    savi.decoder.conv_precision = "fp32"
+    ref = forward_eval(savi, pred, videos, 1, 4, **kw)
+    assert torch.isfinite(out["pred_imgs"]).all()
+    err_cal = max_abs(out["pred_imgs"].cpu(), ref["pred_imgs"].cpu())
+    err_sat = max_abs(saturated["pred_imgs"].cpu(), ref["pred_imgs"].cpu())
+    print(f"pixels vs fp32 path: saturating fp16 planes {err_sat:.2e}, after calibration {err_cal:.2e}")
+    assert err_cal < 2e-2 and err_cal < err_sat / 5
+    # an in-range model is left alone
+    savi2, pred2 = build(7, 4)
+    assert calibrate_precision(savi2, pred2, videos, 1, 4, **kw) == {}
+
+
+@torch.no_grad()
 def test_decode_overlap_is_bit_identical(k7):
     """ decoding on the second stream (the default below 96 sequences) runs the same kernels on the
     same data as the serial order: every output must match bit for bit """

@@ -16,7 +16,7 @@ from .models.Predictors.text_cond_OCVP import TextOCVP_CustomTF, TextOCVP_T5
 from .models.Predictors.OCVP import OCVPSeq, VanillaTransformerPredictor
 
 __all__ = ["setup_model", "setup_predictor", "load_checkpoint", "default_exp_params",
-           "default_dinosaur_params"]
+           "default_dinosaur_params", "calibrate_precision"]
 
 # configs/models/SAVi.json + configs/predictors/TextOCVP_CustomTF.json + CONFIG.py:66-71 defaults
 _SAVI_DEFAULT = {
@@ -142,3 +142,45 @@ def load_checkpoint(checkpoint_path, model, only_model=True, map_cpu=False, **kw
     if not only_model:
         raise NotImplementedError("optimizer / scheduler state is a training feature (not built)")
     return model
+
+
+def calibrate_precision(decomp_model, predictor, videos, num_context, num_preds, **others):
+    """
+    One checked pass over a representative batch that makes the fast arithmetic safe for a given
+    checkpoint.  The fp16-plane modes (f16x3 GEMMs / convs, f16f8 decoder convs) are fp32-class only
+    while |activation| < 255 and |weight| < 63 (operands saturate beyond); this runs the path once with
+    every such kernel checking its operands (kernels._CHECK_RANGE) and, where a check trips, moves the
+    owning module to the range-free arithmetic (decoder convs -> bf16x3, predictor GEMMs -> bf16x6,
+    encoder / DINOSAUR decoder -> fp32 MFMA) and retries.  Returns {module: mode} of what was changed.
+    """
+    from . import kernels as K
+    from .evaluator import forward_eval
+    fallbacks = [
+        (getattr(decomp_model, "decoder", None), "conv_precision", {"f16f8": "bf16x3", "f16x3": "fp32"}),
+        (getattr(decomp_model, "decoder", None), "mlp_precision", {"f16x3": "fp32"}),
+        (getattr(predictor, "predictor", None), "gemm_precision", {"f16x3": "bf16x6"}),
+        (getattr(decomp_model, "encoder", None), "conv_precision", {"f16x3": "fp32"}),
+        (decomp_model, "encoder_gemm_precision", {"f16x3": "fp32"}),
+    ]
+    changed = {}
+    prev, K._CHECK_RANGE = K._CHECK_RANGE, True
+    try:
+        for _ in range(len(fallbacks) + 1):
+            try:
+                forward_eval(decomp_model, predictor, videos, num_context, num_preds,
+                             overlap_decode=False, **others)
+                return changed
+            except K.TocvpError as err:
+                if "range" not in str(err):
+                    raise
+                for mod, attr, table in fallbacks:
+                    cur = getattr(mod, attr, None) if mod is not None else None
+                    if cur in table and (type(mod).__name__, attr) not in changed:
+                        setattr(mod, attr, table[cur])
+                        changed[(type(mod).__name__, attr)] = table[cur]
+                        break
+                else:
+                    raise
+        raise K.TocvpError("calibrate_precision: operands still out of range after every fallback")
+    finally:
+        K._CHECK_RANGE = prev
