@@ -320,6 +320,50 @@ size_t tocvp_metrics_ws_bytes(int N, int C);
 int tocvp_psnr_ssim_f32(const float* preds, const float* targets, float* psnr, float* ssim, int N,
                         int C, int H, int W, int clamp01, void* ws, size_t ws_bytes, void* stream);
 
+/* =============================================================================================
+ * Predictor TRAINING step (reference 04_train_predictor.py:57-108,
+ * lib/loss.py:150-191, lib/setup_model.py:285-332): backward and optimiser kernels.  The forward
+ * pass reuses the inference entry points above.
+ * ============================================================================================= */
+
+/* C[b1,b2] (M x N) = alpha * op(A[b1,b2]) (M x K) * op(B[b1,b2]) (K x N) (+ C if accumulate), exact fp32
+ * MFMA; op = identity / transpose; ld* leading dimensions, s*1 / s*2 batch strides in elements.
+ * Replaces autograd's nn.Linear backward (dW = dY^T X, dX = dY W) and the matmuls of attention backward
+ * (MetaAttention.attention, attention.py:157-176, differentiated). */
+int tocvp_bmm_f32(const float* A, int lda, long sA1, long sA2, int transA, const float* B, int ldb,
+                  long sB1, long sB2, int transB, float* C, int ldc, long sC1, long sC2, int nb1,
+                  int nb2, int M, int N, int K, float alpha, int accumulate, void* stream);
+/* y[r,:] = softmax(scale * x[r,:]) over the first key_len[r / rows_per_batch] (or all) columns, masked
+ * columns 0 (recomputed probabilities of attention backward); ds = scale * p * (dp - <p, dp>). */
+int tocvp_softmax_rows_f32(const float* x, float* y, int rows, int cols, float scale,
+                           const int32_t* key_len, int rows_per_batch, void* stream);
+int tocvp_softmax_bwd_f32(const float* p, const float* dp, float* ds, int rows, int cols, float scale,
+                          void* stream);
+/* y = act(x) and dx = dy * act'(x) for TOCVP_ACT_RELU / TOCVP_ACT_GELU (for ReLU x may be the output) */
+int tocvp_act_f32(const float* x, float* y, long n, int act, void* stream);
+int tocvp_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);
+/* y = a * x + b * y (gradient accumulation, residual adds) */
+int tocvp_axpby_f32(const float* x, float* y, long n, float a, float b, void* stream);
+/* partial[chunk, c] = sum of x[r, c] over the rows of the chunk (bias / parameter gradients; run once
+ * more on `partial` with one chunk for the total) */
+int tocvp_colsum_partial_f32(const float* x, float* partial, int rows, int cols, int ld,
+                             int rows_per_chunk, void* stream);
+/* nn.LayerNorm backward: dx (rows, D) and per-wave partial sums pgamma / pbeta (nwaves, D), nwaves % 4 == 0 */
+int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx,
+                            float* pgamma, float* pbeta, int nwaves, int rows, int D, float eps,
+                            void* stream);
+/* dW[ids[i], :] += dy[i, :]  (nn.Embedding backward; ids < 0 skipped) */
+int tocvp_embedding_bwd_f32(const int64_t* ids, const float* dy, float* dW, int n, int D, void* stream);
+/* nn.MSELoss: partial[b] = block sums of (pred - target)^2 (nblocks of them), dpred = gscale * (pred - target)
+ * when dpred != NULL */
+int tocvp_mse_f32(const float* pred, const float* target, float* partial, int nblocks, float* dpred,
+                  long n, float gscale, void* stream);
+/* partial[b] = block sums of x^2 (clip_grad_norm_) */
+int tocvp_sqnorm_partial_f32(const float* x, float* partial, int nblocks, long n, void* stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) on a flat parameter; g is scaled by gscale first */
+int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                   float beta2, float eps, int step, float gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,326 @@
+// Backward / optimiser kernels of the predictor training step (SURVEY.md section 8f rank 2,
+// reference 04_train_predictor.py:57-108, lib/loss.py:150-191, lib/setup_model.py:285-332).
+// Row-wise HBM-bound kernels: one wave per row, 16-byte accesses, __shfl_xor reductions; column
+// reductions (bias / LayerNorm parameter gradients, loss and norm partials) are deterministic
+// two-stage sums (per-chunk partials in a caller workspace, then one more pass).
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// y[r, :] = softmax(scale * x[r, :]) over the first `len` columns (len = key_len[r / rows_per_batch] or
+// cols); masked columns get probability 0.  One wave per row, cols <= 4096.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int rows, int cols, float scale,
+                                                           const int32_t* __restrict__ key_len,
+                                                           int rows_per_batch) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int len = cols;
+    if (key_len) {
+        len = key_len[row / rows_per_batch];
+        len = len < 1 ? 1 : (len > cols ? cols : len);
+    }
+    const float* xr = x + (size_t)row * cols;
+    float* yr = y + (size_t)row * cols;
+    float m = NEG_BIG;
+    for (int c = lane; c < len; c += 64) m = fmaxf(m, xr[c] * scale);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) s += expf(xr[c] * scale - m);
+    s = wave_sum64(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < cols; c += 64) yr[c] = c < len ? expf(xr[c] * scale - m) * inv : 0.f;
+}
+
+// ds = scale * p * (dp - sum_j p_j dp_j)   (softmax backward w.r.t. the pre-scale scores)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                          float* __restrict__ ds, int rows, int cols,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = p + (size_t)row * cols;
+    const float* dr = dp + (size_t)row * cols;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot += pr[c] * dr[c];
+    dot = wave_sum64(dot);
+    float* o = ds + (size_t)row * cols;
+    for (int c = lane; c < cols; c += 64) o[c] = scale * pr[c] * (dr[c] - dot);
+}
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+// act 1 = ReLU, 2 = exact GELU
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                      int act) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = act == 1 ? fmaxf(v, 0.f) : gelu_f(v);
+}
+// dx = dy * act'(x); for ReLU `x` may be the activation OUTPUT (same sign test)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      float* __restrict__ dx, long n, int act) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    dx[i] = act == 1 ? (v > 0.f ? dy[i] : 0.f) : dy[i] * gelu_grad(v);
+}
+
+// y = a * x + b * y
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                    float a, float b) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+// partial[chunk, c] = sum over the rows of the chunk of x[r, c]; grid (ceil(cols/256), chunks)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                             int rows, int cols, int ld, int rows_per_chunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c];
+    partial[(size_t)blockIdx.y * cols + c] = s;
+}
+
+// LayerNorm backward, one wave per row (D <= 1024, D % 4 == 0):
+//   xhat = (x - mean) * rstd;  g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// and per-wave partial sums of dgamma = sum dy * xhat, dbeta = sum dy over the rows this wave visits.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ pgamma, float* __restrict__ pbeta,
+                                                            int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    f32x4 ag[4], ab[4], gm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = (lane + 64 * i) * 4;
+        gm[i] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = wid; row < rows; row += nw) {
+        f32x4 v[4], d[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            v[i] = c < D ? *reinterpret_cast<const f32x4*>(x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = c < D ? *reinterpret_cast<const f32x4*>(dy + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum64(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q += (v[i][u] - mean) * (v[i][u] - mean);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)D + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xh = (v[i][u] - mean) * rstd;
+                    const float g = d[i][u] * gm[i][u];
+                    sg += g;
+                    sgx += g * xh;
+                    ag[i][u] += d[i][u] * xh;
+                    ab[i][u] += d[i][u];
+                    v[i][u] = xh;                       // keep xhat for the dx pass
+                }
+        }
+        const float mg = wave_sum64(sg) / (float)D, mgx = wave_sum64(sgx) / (float)D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = rstd * (d[i][u] * gm[i][u] - mg - v[i][u] * mgx);
+                *reinterpret_cast<f32x4*>(dx + (size_t)row * D + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            *reinterpret_cast<f32x4*>(pgamma + (size_t)wid * D + c) = ag[i];
+            *reinterpret_cast<f32x4*>(pbeta + (size_t)wid * D + c) = ab[i];
+        }
+    }
+}
+
+// dW[ids[i], :] += dy[i, :]  (token embedding gradient; ids < 0 skipped)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy,
+                                                            float* __restrict__ dW, int n, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)n * D) return;
+    const int r = (int)(i / D), c = (int)(i % D);
+    const long id = ids[r];
+    if (id >= 0) atomicAdd(dW + id * D + c, dy[i]);
+}
+
+// MSE (mean over all n elements): partial[b] = sum over block b of (p - t)^2;  dp = gscale * (p - t)
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ tg,
+                                                  float* __restrict__ partial, float* __restrict__ dp, long n,
+                                                  float gscale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = p[i] - tg[i];
+        s += d * d;
+        if (dp) dp[i] = gscale * d;
+    }
+    s = wave_sum64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[b] = sum over block b of x^2
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, float* __restrict__ partial, long n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): g' = gscale * g (gradient clipping factor)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2,
+                                                   float gscale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+inline unsigned blocks256(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int tocvp_softmax_rows_f32(const float* x, float* y, int rows, int cols, float scale,
+                                      const int32_t* key_len, int rows_per_batch, void* stream) {
+    TOCVP_CHECK_ARG(x && y && rows >= 0 && cols > 0 && (key_len == nullptr || rows_per_batch > 0));
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, y, rows, cols, scale, key_len, rows_per_batch);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_softmax_bwd_f32(const float* p, const float* dp, float* ds, int rows, int cols,
+                                     float scale, void* stream) {
+    TOCVP_CHECK_ARG(p && dp && ds && rows >= 0 && cols > 0);
+    if (rows == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       p, dp, ds, rows, cols, scale);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_act_f32(const float* x, float* y, long n, int act, void* stream) {
+    TOCVP_CHECK_ARG(x && y && n >= 0 && (act == TOCVP_ACT_RELU || act == TOCVP_ACT_GELU));
+    if (n == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n,
+                       act);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream) {
+    TOCVP_CHECK_ARG(dy && x && dx && n >= 0 && (act == TOCVP_ACT_RELU || act == TOCVP_ACT_GELU));
+    if (n == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, dx,
+                       n, act);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_axpby_f32(const float* x, float* y, long n, float a, float b, void* stream) {
+    TOCVP_CHECK_ARG(x && y && n >= 0);
+    if (n == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, a, b);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_colsum_partial_f32(const float* x, float* partial, int rows, int cols, int ld,
+                                        int rows_per_chunk, void* stream) {
+    TOCVP_CHECK_ARG(x && partial && rows > 0 && cols > 0 && ld >= cols && rows_per_chunk > 0);
+    const int chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+    TOCVP_CHECK_ARG(chunks <= 65535);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, partial, rows, cols, ld, rows_per_chunk);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx,
+                                       float* pgamma, float* pbeta, int nwaves, int rows, int D, float eps,
+                                       void* stream) {
+    TOCVP_CHECK_ARG(x && gamma && dy && dx && pgamma && pbeta);
+    TOCVP_CHECK_ARG(rows > 0 && D > 0 && D <= 1024 && (D & 3) == 0 && nwaves > 0 && (nwaves & 3) == 0);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(dy) || !tocvp_aligned16(dx) || !tocvp_aligned16(gamma) ||
+        !tocvp_aligned16(pgamma) || !tocvp_aligned16(pbeta))
+        return TOCVP_EALIGN;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nwaves / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       gamma, dy, dx, pgamma, pbeta, rows, D, eps);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_embedding_bwd_f32(const int64_t* ids, const float* dy, float* dW, int n, int D,
+                                       void* stream) {
+    TOCVP_CHECK_ARG(ids && dy && dW && n >= 0 && D > 0);
+    if (n == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks256((long)n * D)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ids, dy, dW, n, D);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_mse_f32(const float* pred, const float* target, float* partial, int nblocks, float* dpred,
+                             long n, float gscale, void* stream) {
+    TOCVP_CHECK_ARG(pred && target && partial && nblocks > 0 && n > 0);
+    hipLaunchKernelGGL(mse_kernel, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target,
+                       partial, dpred, n, gscale);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_sqnorm_partial_f32(const float* x, float* partial, int nblocks, long n, void* stream) {
+    TOCVP_CHECK_ARG(x && partial && nblocks > 0 && n > 0);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, partial, n);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                              float beta2, float eps, int step, float gscale, void* stream) {
+    TOCVP_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1);
+    if (n == 0) return TOCVP_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       n, lr, beta1, beta2, eps, bc1, bc2, gscale);
+    return tocvp_launch_status();
+}

@@ -1,0 +1,355 @@
+"""
+Minimal tape autograd over the HIP kernels, for the predictor training step (SURVEY.md section 8f
+rank 2; reference 04_train_predictor.py:57-108).  torch.autograd is not used: every forward op
+calls a libtocvp kernel and records a closure that calls the matching backward kernels; gradient
+accumulation is an axpby kernel.  torch provides device memory (empty / clone / index copies) only.
+
+    tape = Tape()
+    y = linear(tape, x, W, b, act=ACT_RELU)
+    ...
+    loss = mse(tape, pred, target)          # python float + seeds d(loss)/d(pred)
+    tape.backward()                         # walks the closures in reverse
+"""
+
+import torch
+
+from .. import kernels as K
+
+__all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "add", "activation", "add_position_rows",
+           "stack_frames", "take_frame", "embedding", "mask_rows", "mse", "accumulate", "bmm"]
+
+_L = K.lib
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Var:
+    """ a tensor on the tape: ``data`` (contiguous fp32 CUDA), ``grad`` (None until something flows in) """
+    __slots__ = ("data", "grad", "requires_grad", "name")
+
+    def __init__(self, data, requires_grad=False, name=None):
+        assert data.is_cuda and data.dtype == torch.float32
+        self.data = data if data.is_contiguous() else data.contiguous()
+        self.grad, self.requires_grad, self.name = None, requires_grad, name
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class Tape:
+    def __init__(self):
+        self.nodes = []
+
+    def record(self, fn):
+        self.nodes.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+
+
+# ------------------------------------------------------------------------------------------------
+# raw kernel wrappers
+# ------------------------------------------------------------------------------------------------
+def axpby(x, y, a=1.0, b=1.0):
+    """ y = a * x + b * y (in place on y) """
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    K._check(_L().tocvp_axpby_f32(_p(x), _p(y), x.numel(), float(a), float(b), _s()), "tocvp_axpby_f32")
+    return y
+
+
+def accumulate(var, g):
+    """ add gradient ``g`` (same shape as var.data) into var.grad; takes ownership of ``g`` when it is the first """
+    if not var.requires_grad:
+        return
+    g = g.reshape(var.data.shape)
+    if var.grad is None:
+        var.grad = g if g.is_contiguous() else g.contiguous()
+    else:
+        axpby(g if g.is_contiguous() else g.contiguous(), var.grad, 1.0, 1.0)
+
+
+def bmm(A, B, C, M, N, Kd, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
+        sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, acc=False):
+    K._check(_L().tocvp_bmm_f32(_p(A), lda, sA[0], sA[1], int(transA), _p(B), ldb, sB[0], sB[1], int(transB),
+                                _p(C), ldc, sC[0], sC[1], batch[0], batch[1], M, N, Kd, float(alpha),
+                                int(acc), _s()), "tocvp_bmm_f32")
+    return C
+
+
+def colsum(x2, out=None, acc=False):
+    """ x2 (rows, cols) contiguous -> (cols,) column sums, deterministic two-stage """
+    rows, cols = x2.shape
+    chunk = 512
+    nch = (rows + chunk - 1) // chunk
+    part = torch.empty((nch, cols), device=x2.device, dtype=torch.float32)
+    K._check(_L().tocvp_colsum_partial_f32(_p(x2), _p(part), rows, cols, cols, chunk, _s()),
+             "tocvp_colsum_partial_f32")
+    res = torch.empty((1, cols), device=x2.device, dtype=torch.float32)
+    K._check(_L().tocvp_colsum_partial_f32(_p(part), _p(res), nch, cols, cols, nch, _s()),
+             "tocvp_colsum_partial_f32")
+    res = res.reshape(cols)
+    if out is None:
+        return res
+    return axpby(res, out, 1.0, 1.0 if acc else 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable ops
+# ------------------------------------------------------------------------------------------------
+def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
+    """ y = act(x W^T + b); x (..., K), W (N, K).  ReLU is fused; GELU keeps the pre-activation. """
+    N, Kd = W.data.shape
+    fused = act if act == K.ACT_RELU else K.ACT_NONE
+    pre = K.linear(x.data, W.data, None if b is None else b.data, act=fused, precision=precision)
+    y = pre
+    if act == K.ACT_GELU:
+        y = torch.empty_like(pre)
+        K._check(_L().tocvp_act_f32(_p(pre), _p(y), pre.numel(), K.ACT_GELU, _s()), "tocvp_act_f32")
+    out = Var(y, x.requires_grad or W.requires_grad or (b is not None and b.requires_grad))
+    if not out.requires_grad:
+        return out
+
+    def backward():
+        if out.grad is None:
+            return
+        g = out.grad.reshape(-1, N)
+        if act != K.ACT_NONE:
+            gg = torch.empty_like(g)
+            K._check(_L().tocvp_act_bwd_f32(_p(g), _p(pre), _p(gg), g.numel(), int(act), _s()),
+                     "tocvp_act_bwd_f32")
+            g = gg
+        M = g.shape[0]
+        x2 = x.data.reshape(M, Kd)
+        if W.requires_grad:                               # dW (N, K) = g^T (N, M) x (M, K)
+            if W.grad is None:
+                W.grad = torch.empty_like(W.data)
+                bmm(g, x2, W.grad, N, Kd, M, N, Kd, Kd, transA=True)
+            else:
+                bmm(g, x2, W.grad, N, Kd, M, N, Kd, Kd, transA=True, acc=True)
+        if b is not None and b.requires_grad:
+            if b.grad is None:
+                b.grad = colsum(g)
+            else:
+                colsum(g, out=b.grad, acc=True)
+        if x.requires_grad:                               # dx (M, K) = g (M, N) W (N, K)
+            dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
+            bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
+            accumulate(x, dx)
+    tape.record(backward)
+    return out
+
+
+def activation(tape, x, act):
+    y = torch.empty_like(x.data)
+    K._check(_L().tocvp_act_f32(_p(x.data), _p(y), y.numel(), int(act), _s()), "tocvp_act_f32")
+    out = Var(y, x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            dx = torch.empty_like(x.data)
+            K._check(_L().tocvp_act_bwd_f32(_p(out.grad), _p(x.data), _p(dx), dx.numel(), int(act), _s()),
+                     "tocvp_act_bwd_f32")
+            accumulate(x, dx)
+        tape.record(backward)
+    return out
+
+
+def layer_norm(tape, x, gamma, beta, eps):
+    y = K.layer_norm(x.data, gamma.data, beta.data, eps)
+    out = Var(y, x.requires_grad or gamma.requires_grad or beta.requires_grad)
+    if not out.requires_grad:
+        return out
+    D = x.data.shape[-1]
+
+    def backward():
+        if out.grad is None:
+            return
+        rows = x.data.numel() // D
+        nwaves = min(1024, (rows + 3) // 4 * 4)
+        nwaves = max(4, nwaves // 4 * 4)
+        dx = torch.empty_like(x.data)
+        pg = torch.empty((nwaves, D), device=dx.device, dtype=torch.float32)
+        pb = torch.empty((nwaves, D), device=dx.device, dtype=torch.float32)
+        K._check(_L().tocvp_layernorm_bwd_f32(_p(x.data), _p(gamma.data), _p(out.grad), _p(dx), _p(pg), _p(pb),
+                                              nwaves, rows, D, float(eps), _s()), "tocvp_layernorm_bwd_f32")
+        if gamma.requires_grad:
+            accumulate(gamma, colsum(pg))
+        if beta.requires_grad:
+            accumulate(beta, colsum(pb))
+        accumulate(x, dx)
+    tape.record(backward)
+    return out
+
+
+def attention(tape, q, k, v, heads, scale, key_len=None):
+    """ multi-head softmax attention: q (B, Tq, E), k / v (B, Tk, E) separate contiguous tensors """
+    B, Tq, E = q.data.shape
+    Tk = k.data.shape[1]
+    dh = E // heads
+    o = K.mha(q.data, k.data, v.data, heads, scale, key_len=key_len)
+    out = Var(o, q.requires_grad or k.requires_grad or v.requires_grad)
+    if not out.requires_grad:
+        return out
+
+    def backward():
+        if out.grad is None:
+            return
+        dO = out.grad
+        dev = dO.device
+        hb = (B, heads)
+        sQ, sK = (Tq * E, dh), (Tk * E, dh)
+        sS = (heads * Tq * Tk, Tq * Tk)
+        S = torch.empty((B, heads, Tq, Tk), device=dev, dtype=torch.float32)
+        bmm(q.data, k.data, S, Tq, Tk, dh, E, E, Tk, transB=True, batch=hb, sA=sQ, sB=sK, sC=sS)
+        K._check(_L().tocvp_softmax_rows_f32(_p(S), _p(S), B * heads * Tq, Tk, float(scale), _p(key_len),
+                                             heads * Tq, _s()), "tocvp_softmax_rows_f32")
+        if v.requires_grad:                               # dV = P^T dO
+            dV = torch.empty_like(v.data)
+            bmm(S, dO, dV, Tk, dh, Tq, Tk, E, E, transA=True, batch=hb, sA=sS, sB=sQ, sC=sK)
+            accumulate(v, dV)
+        if q.requires_grad or k.requires_grad:
+            dP = torch.empty_like(S)                      # dP = dO V^T, then dS in place
+            bmm(dO, v.data, dP, Tq, Tk, dh, E, E, Tk, transB=True, batch=hb, sA=sQ, sB=sK, sC=sS)
+            K._check(_L().tocvp_softmax_bwd_f32(_p(S), _p(dP), _p(dP), B * heads * Tq, Tk, float(scale), _s()),
+                     "tocvp_softmax_bwd_f32")
+            if q.requires_grad:                           # dQ = dS K
+                dQ = torch.empty_like(q.data)
+                bmm(dP, k.data, dQ, Tq, dh, Tk, Tk, E, E, batch=hb, sA=sS, sB=sK, sC=sQ)
+                accumulate(q, dQ)
+            if k.requires_grad:                           # dK = dS^T Q
+                dK = torch.empty_like(k.data)
+                bmm(dP, q.data, dK, Tk, dh, Tq, Tk, E, E, transA=True, batch=hb, sA=sS, sB=sQ, sC=sK)
+                accumulate(k, dK)
+    tape.record(backward)
+    return out
+
+
+def add(tape, a, b):
+    y = a.data.clone()
+    axpby(b.data, y, 1.0, 1.0)
+    out = Var(y, a.requires_grad or b.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            if a.requires_grad and b.requires_grad:
+                accumulate(a, out.grad.clone())
+                accumulate(b, out.grad)
+            else:
+                accumulate(a if a.requires_grad else b, out.grad)
+        tape.record(backward)
+    return out
+
+
+def add_position_rows(tape, x, table, index):
+    """ x (B, w, ...rest) + table[index[pos]] broadcast over B and the inner axes; table (P, E), E = last axis """
+    B, w = x.data.shape[:2]
+    E = x.data.shape[-1]
+    idx = torch.as_tensor(index, device=x.data.device, dtype=torch.int64)
+    rows = table.data.index_select(0, idx)                             # (w, E) gather (data movement)
+    shape = [1, w] + [1] * (x.data.dim() - 3) + [E]
+    addend = rows.reshape(shape).expand_as(x.data).contiguous()
+    y = x.data.clone()
+    axpby(addend, y, 1.0, 1.0)
+    out = Var(y, x.requires_grad or table.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            if table.requires_grad:
+                if table.grad is None:
+                    table.grad = torch.zeros_like(table.data)
+                g = out.grad.reshape(B, w, -1, E).permute(1, 0, 2, 3).contiguous()   # (w, B, inner, E)
+                for pos in range(w):
+                    colsum(g[pos].reshape(-1, E), out=table.grad[int(index[pos])], acc=True)
+            if x.requires_grad:
+                accumulate(x, out.grad)
+        tape.record(backward)
+    return out
+
+
+def stack_frames(tape, frames):
+    """ list of Vars (B, K, D) -> Var (B, w, K, D) """
+    y = torch.stack([f.data for f in frames], dim=1).contiguous()
+    out = Var(y, any(f.requires_grad for f in frames))
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            for i, f in enumerate(frames):
+                if f.requires_grad:
+                    accumulate(f, out.grad[:, i].contiguous())
+        tape.record(backward)
+    return out
+
+
+def take_frame(tape, x, i):
+    """ x (B, w, K, E) -> frame i (B, K, E) """
+    y = x.data[:, i].contiguous()
+    out = Var(y, x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            g = torch.zeros_like(x.data)
+            g[:, i] = out.grad
+            accumulate(x, g)
+        tape.record(backward)
+    return out
+
+
+def embedding(tape, ids, table):
+    y = K.embedding(ids, table.data)
+    out = Var(y, table.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            if table.grad is None:
+                table.grad = torch.zeros_like(table.data)
+            D = table.data.shape[1]
+            K._check(_L().tocvp_embedding_bwd_f32(_p(ids), _p(out.grad), _p(table.grad), ids.numel(), D, _s()),
+                     "tocvp_embedding_bwd_f32")
+        tape.record(backward)
+    return out
+
+
+def mask_rows(tape, x, keep):
+    """ zero the rows of x (..., E) where ``keep`` (..., bool) is False (caption padding) """
+    y = x.data.clone()
+    y.masked_fill_(~keep.unsqueeze(-1), 0.0)
+    out = Var(y, x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            g = out.grad.clone()
+            g.masked_fill_(~keep.unsqueeze(-1), 0.0)
+            accumulate(x, g)
+        tape.record(backward)
+    return out
+
+
+def mse(tape, pred, target, weight=1.0):
+    """ weight * mean((pred - target)^2); returns the python float and seeds pred.grad """
+    n = pred.data.numel()
+    nblocks = min(1024, (n + 255) // 256)
+    part = torch.empty(nblocks, device=pred.data.device, dtype=torch.float32)
+    dp = torch.empty_like(pred.data) if pred.requires_grad else None
+    tgt = target if target.is_contiguous() else target.contiguous()
+    K._check(_L().tocvp_mse_f32(_p(pred.data), _p(tgt), _p(part), nblocks, _p(dp), n, 2.0 * weight / n, _s()),
+             "tocvp_mse_f32")
+    total = colsum(part.reshape(nblocks, 1))
+    if dp is not None:
+        tape.record(lambda: accumulate(pred, dp))
+    return total, float(weight) / n
