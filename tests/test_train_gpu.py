@@ -128,3 +128,50 @@ def test_position_rows_embedding_mse_and_accumulation():
     Eo.grad = ge.to(DEV)
     tape.backward()
     assert rel_err(T.grad, tr.grad) < 1e-5
+
+
+def _predictor_setup(num_slots=7, num_preds=3, B=2):
+    from textocvp_amd.setup_model import default_exp_params, setup_predictor
+    exp = default_exp_params(num_slots=num_slots, num_context=1, num_preds=num_preds)
+    pred = setup_predictor(exp)
+    synth.fill_module_(pred, prefix="pred.")
+    hist = synth.synth_tensor("train.hist", (B, 1 + num_preds, num_slots, 128), "normal")
+    tokens, lengths = synth.synth_captions(B, max_len=12, lengths=[9, 12][:B], seed=0)
+    return exp, pred, hist, tokens, lengths
+
+
+def test_predictor_rollout_gradients_match_oracle_autograd():
+    """ slot-MSE loss through the 3-step autoregressive rollout (BPTT, text encoder included): every
+    parameter gradient of the tape autograd equals torch.autograd applied to the CPU oracle (fp64) """
+    from oracle import slot_rollout_oracle as O
+    from textocvp_amd.train import autograd as ag
+    from textocvp_amd.train.predictor import TrainablePredictor
+    exp, pred, hist, tokens, lengths = _predictor_setup()
+    P = 3
+    sd = {k: v.detach().double().clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in pred.state_dict().items()}
+    ref_preds = O.rollout(sd, hist.double(), tokens, lengths, 1, P)
+    target = hist[:, 1:1 + P]
+    ref_loss = F.mse_loss(ref_preds, target.double())
+    ref_loss.backward()
+
+    pred = pred.to(DEV)
+    tp = TrainablePredictor(pred)
+    tape = ag.Tape()
+    preds = tp.rollout(tape, hist.to(DEV), tokens.to(DEV), lengths.to(DEV), P)
+    stacked = ag.stack_frames(tape, preds)
+    total, sc = ag.mse(tape, stacked, target.to(DEV))
+    tape.backward()
+    assert abs(total.item() * sc - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    assert rel_err(stacked.data, ref_preds) < 1e-4
+    worst = 0.0
+    for name, var in tp.names.items():
+        ref = sd[name].grad
+        if ref is None:
+            assert var.grad is None or var.grad.abs().max().item() == 0.0, name
+            continue
+        assert var.grad is not None, name
+        e = rel_err(var.grad, ref)
+        worst = max(worst, e)
+        assert e < 2e-3, (name, e)
+    print(f"predictor BPTT gradients: worst relative error {worst:.2e} over {len(tp.names)} tensors")

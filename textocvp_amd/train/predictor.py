@@ -1,0 +1,146 @@
+"""
+Differentiable TextOCVP_CustomTF rollout on the tape autograd (reference forward:
+models/Predictors/predictor_wrapper.py:50-87, text_cond_OCVP.py:79-105, Blocks/attention.py:504-524,
+EncodersDecoders/text_encoders.py:89-125; differentiated by hand here instead of torch.autograd).
+
+The modules of ``textocvp_amd.models`` are the parameter containers: every ``nn.Parameter`` is wrapped
+in a ``Var`` that aliases its storage, so the optimiser updates the model in place and the inference
+path sees the trained weights.  Full back-propagation through time: predicted slots are fed back into
+the window without detaching, as in the reference.
+"""
+
+import torch
+
+from .. import kernels as K
+from . import autograd as ag
+
+__all__ = ["TrainablePredictor"]
+
+
+def _split_last(tape, x, n):
+    """ x (..., n * E) -> n Vars (..., E) (contiguous copies); backward concatenates the gradients """
+    E = x.data.shape[-1] // n
+    parts = [ag.Var(x.data[..., i * E:(i + 1) * E].contiguous(), x.requires_grad) for i in range(n)]
+    if x.requires_grad:
+        def backward():
+            if all(p.grad is None for p in parts):
+                return
+            g = torch.zeros_like(x.data)
+            for i, p in enumerate(parts):
+                if p.grad is not None:
+                    g[..., i * E:(i + 1) * E] = p.grad
+            ag.accumulate(x, g)
+        tape.record(backward)
+    return parts
+
+
+class TrainablePredictor:
+    def __init__(self, wrapper, precision="f16x3"):
+        self.wrapper = wrapper
+        self.pred = wrapper.predictor
+        if type(self.pred).__name__ != "TextOCVP_CustomTF":
+            raise NotImplementedError("training step: TextOCVP_CustomTF only (reference config 5)")
+        self.precision = precision
+        self.vars = {}
+        self.names = {}
+        for name, p in wrapper.named_parameters():
+            v = ag.Var(p.data, requires_grad=True, name=name)
+            self.vars[id(p)] = v
+            self.names[name] = v
+
+    def V(self, param):
+        return self.vars[id(param)]
+
+    def zero_grad(self):
+        for v in self.vars.values():
+            v.grad = None
+
+    # ---------------------------------------------------------------------------------------
+    def _lin(self, tape, x, mod, act=K.ACT_NONE):
+        return ag.linear(tape, x, self.V(mod.weight), None if mod.bias is None else self.V(mod.bias), act=act,
+                         precision=self.precision)
+
+    def _ln(self, tape, x, mod):
+        return ag.layer_norm(tape, x, self.V(mod.weight), self.V(mod.bias), mod.eps)
+
+    def encode_text(self, tape, tokens, lengths):
+        """ TransformerTextEncoder.forward (text_encoders.py:89-125) """
+        te = self.pred.text_encoder
+        B, L = tokens.shape
+        key_len = lengths.to(device=tokens.device, dtype=torch.int32).contiguous()
+        x = ag.embedding(tape, tokens, self.V(te.token_embedding.weight))
+        x = ag.add_position_rows(tape, x, self.V(te.position_embedding.weight), list(range(L)))
+        x = self._ln(tape, x, te.layer_norm)
+        x = ag.mask_rows(tape, x, tokens != 0)
+        E = x.data.shape[-1]
+        H = te.num_heads
+        for layer in te.transformer.layers:
+            sa = layer.self_attn
+            qkv = ag.linear(tape, x, self.V(sa.in_proj_weight), self.V(sa.in_proj_bias), precision=self.precision)
+            q, k, v = _split_last(tape, qkv, 3)
+            a = ag.attention(tape, q, k, v, H, (E // H) ** -0.5, key_len=key_len)
+            x = self._ln(tape, ag.add(tape, self._lin(tape, a, sa.out_proj), x), layer.norm1)
+            h = self._lin(tape, x, layer.linear1, act=K.ACT_GELU)
+            x = self._ln(tape, ag.add(tape, self._lin(tape, h, layer.linear2), x), layer.norm2)
+        return self._lin(tape, self._ln(tape, x, te.text_out_projection[0]), te.text_out_projection[1])
+
+    def _self_attention(self, tape, x, attn):
+        E = x.data.shape[-1]
+        q, k, v = (self._lin(tape, x, m) for m in (attn.q, attn.k, attn.v))
+        o = ag.attention(tape, q, k, v, attn.num_heads, (E // attn.num_heads) ** -0.5)
+        return self._lin(tape, o, attn.out_projection[0])
+
+    def _mlp(self, tape, x, seq):
+        return self._lin(tape, self._lin(tape, x, seq[0], act=K.ACT_RELU), seq[2])
+
+    def _block(self, tape, x, blk, text):
+        """ AdaptedEncoderBlock.forward (attention.py:504-524): note the final residual from y """
+        y = ag.add(tape, self._self_attention(tape, self._ln(tape, x, blk.layernorm_query), blk.attn), x)
+        cb = blk.cross_attention
+        ca = cb.cross_attn
+        tn = self._ln(tape, text, cb.ln_cross_att_kv)
+        q = self._lin(tape, self._ln(tape, y, cb.ln_cross_att_q), ca.q)
+        k, v = self._lin(tape, tn, ca.k), self._lin(tape, tn, ca.v)
+        o = ag.attention(tape, q, k, v, ca.num_heads, ca.dim_head ** -0.5)      # padded text attends too
+        z1 = ag.add(tape, self._lin(tape, o, ca.out_projection), y)
+        z = ag.add(tape, self._mlp(tape, self._ln(tape, z1, cb.ln_mlp), cb.mlp), z1)
+        return ag.add(tape, self._mlp(tape, self._ln(tape, z, blk.layernorm_mlp), blk.mlp), y)
+
+    def step(self, tape, window, text):
+        """ BaseTextOCVP.forward: window = list of frame Vars (B, K, D) -> next-slot Var (B, K, D) """
+        p = self.pred
+        w = len(window)
+        slots = ag.stack_frames(tape, window)                                   # (B, w, K, D)
+        B, _, Ks, _ = slots.data.shape
+        tokens = self._lin(tape, slots, p.mlp_in)                               # (B, w, K, E)
+        pe = self.V(p.pe.pe)
+        table = ag.Var(pe.data.reshape(-1, pe.data.shape[-1]), pe.requires_grad)
+        if pe.grad is None:
+            pe.grad = torch.zeros_like(pe.data)
+        table.grad = pe.grad.reshape(table.data.shape)                          # same storage as pe.grad
+        tokens = ag.add_position_rows(tape, tokens, table, [w - 1 - i for i in range(w)])
+        E = tokens.data.shape[-1]
+        x = ag.Var(tokens.data.reshape(B, w * Ks, E), tokens.requires_grad)
+        tape.record(lambda xv=x, tv=tokens: ag.accumulate(tv, xv.grad) if xv.grad is not None else None)
+        for blk in p.predictor:
+            x = self._block(tape, x, blk, text)
+        x4 = ag.Var(x.data.reshape(B, w, Ks, E), x.requires_grad)
+        tape.record(lambda xv=x, x4v=x4: ag.accumulate(xv, x4v.grad) if x4v.grad is not None else None)
+        last = ag.take_frame(tape, x4, w - 1)
+        out = self._lin(tape, last, p.mlp_out)
+        return ag.add(tape, out, window[-1]) if p.residual else out
+
+    def rollout(self, tape, slot_history, tokens, lengths, num_preds=None):
+        """ PredictorWrapper.forward: returns the list of predicted-slot Vars (B, K, D) """
+        wr = self.wrapper
+        num_preds = wr.num_preds if num_preds is None else num_preds
+        text = self.encode_text(tape, tokens, lengths)
+        window = [ag.Var(slot_history[:, i].contiguous()) for i in range(wr.num_context)]
+        preds = []
+        teacher = wr.exp_params["prediction_params"]["teacher_force"]
+        for t in range(num_preds):
+            cur = self.step(tape, window, text)
+            nxt = ag.Var(slot_history[:, wr.num_context + t].contiguous()) if teacher else cur
+            window = (window + [nxt])[-wr.input_buffer_size:]
+            preds.append(cur)
+        return preds
