@@ -360,6 +360,19 @@ int tocvp_mse_f32(const float* pred, const float* target, float* partial, int nb
                   long n, float gscale, void* stream);
 /* partial[b] = block sums of x^2 (clip_grad_norm_) */
 int tocvp_sqnorm_partial_f32(const float* x, float* partial, int nblocks, long n, void* stream);
+/* Frozen SAVi decoder, backward w.r.t. the slots (image-loss term; SAVi.py:241-275 differentiated):
+ *  tocvp_dec_tail_grad_f32: dimg (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W) -> dy (F*K,H,W,4) =
+ *    gradient of the tail conv's output (rgb | alpha) through compositing and the softmax over slots;
+ *  tocvp_conv3x3_t4_f32: dx (n,H,W,C) = relu'(act) * conv_transpose3x3(dy (n,H,W,4), w (4,C,3,3));
+ *  tocvp_dec_class_reduce_f32: dS (n,25,64) = per-border-class sums of g (n,H,W,64) * (cpos + S > 0)
+ *    (collapsed decoder layer 0, see tocvp_dec_tapsum_f32).
+ * The 5x5 data gradients in between reuse tocvp_conv5x5_bf16x3_f32 with transposed, flipped weights. */
+int tocvp_dec_tail_grad_f32(const float* dimg, const float* recons, const float* masks, float* dy, int F,
+                            int K, int H, int W, void* stream);
+int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float* act, float* dx, int nimg, int H,
+                         int W, int C, void* stream);
+int tocvp_dec_class_reduce_f32(const float* g, const float* cpos, const float* S, float* dS, int nimg,
+                               int H, int W, int C, void* stream);
 /* torch.optim.Adam step (no weight decay / amsgrad) on a flat parameter; g is scaled by gscale first */
 int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                    float beta2, float eps, int step, float gscale, void* stream);

@@ -175,3 +175,72 @@ def test_predictor_rollout_gradients_match_oracle_autograd():
         worst = max(worst, e)
         assert e < 2e-3, (name, e)
     print(f"predictor BPTT gradients: worst relative error {worst:.2e} over {len(tp.names)} tensors")
+
+
+def test_training_step_gradients_with_image_loss_match_oracle_autograd():
+    """ the full loss of 04_train_predictor.py (image MSE through the frozen SAVi decoder + slot MSE):
+    parameter gradients against torch.autograd on the CPU oracle, then one clipped Adam step
+    against torch.optim.Adam on those reference gradients """
+    from oracle import slot_rollout_oracle as O
+    from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
+    from textocvp_amd.train.step import PredictorTrainStep
+    Ks, P, B = 7, 2, 2
+    exp = default_exp_params(num_slots=Ks, num_context=1, num_preds=P)
+    savi, pred = setup_model(exp["model"]).eval(), setup_predictor(exp)
+    synth.fill_module_(savi, prefix="savi.")
+    synth.fill_module_(pred, prefix="pred.")
+    videos = synth.synth_videos(B, 1 + P, seed=0)
+    tokens, lengths = synth.synth_captions(B, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(B, Ks, 128, seed=1)
+
+    # reference: the CPU oracle (fp32, its SAVi half is not dtype-generic) differentiated by torch.autograd
+    # on the predictor weights only (SAVi frozen)
+    savi_sd = {k: v.detach() for k, v in savi.state_dict().items()}
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in pred.state_dict().items()}
+    with torch.no_grad():
+        hist = O.savi_decomp(savi_sd, videos, noise, 1 + P)
+    preds = O.rollout(sd, hist, tokens, lengths, 1, P)
+    imgs, _, _ = O.savi_decode(savi_sd, preds.reshape(B * P, Ks, 128), (64, 64), 3)
+    l_img = F.mse_loss(imgs.view(B, P, 3, 64, 64), videos[:, 1:1 + P])
+    l_slot = F.mse_loss(preds, hist[:, 1:1 + P])
+    (l_img + l_slot).backward()
+
+    savi, pred = savi.to(DEV), pred.to(DEV)
+    ts = PredictorTrainStep(savi, pred, lr=1e-4, clip=0.05, warmup_steps=0)
+    losses = ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+    assert abs(losses["pred_img_mse"] - l_img.item()) < 2e-4 * abs(l_img.item())
+    assert abs(losses["pred_slot_mse"] - l_slot.item()) < 2e-4 * abs(l_slot.item())
+    worst, gref = 0.0, {}
+    for name, var in ts.model.names.items():
+        ref = sd[name].grad
+        gref[name] = torch.zeros_like(sd[name]) if ref is None else ref
+        if ref is None:
+            assert var.grad is None or var.grad.abs().max().item() == 0.0, name
+            continue
+        e = rel_err(var.grad, ref)
+        worst = max(worst, e)
+        assert e < 5e-3, (name, e)
+    print(f"training step (image + slot loss): worst relative gradient error {worst:.2e}; "
+          f"losses img {losses['pred_img_mse']:.5f} slot {losses['pred_slot_mse']:.5f}")
+
+    # optimiser: clip_grad_norm_(0.05) + Adam against torch.optim.Adam fed with the SAME gradients (the first
+    # Adam step is ~lr * sign(g): elements with |g| ~ eps would otherwise amplify the 1e-6 gradient noise)
+    before = {n: v.data.detach().cpu().double().clone() for n, v in ts.model.names.items()}
+    mine = {n: (torch.zeros_like(before[n]) if v.grad is None else v.grad.detach().cpu().double().clone())
+            for n, v in ts.model.names.items()}
+    norm, lr = ts.apply()
+    ref_params = [torch.nn.Parameter(before[n].clone()) for n in ts.model.names]
+    for p_, n in zip(ref_params, ts.model.names):
+        p_.grad = mine[n].clone()
+    ref_norm = torch.nn.utils.clip_grad_norm_(ref_params, 0.05)
+    torch.optim.Adam(ref_params, lr=1e-4).step()
+    assert abs(norm - ref_norm.item()) < 1e-4 * ref_norm.item()
+    for p_, (n, v) in zip(ref_params, ts.model.names.items()):
+        upd_ref = (p_.detach() - before[n])
+        upd = v.data.detach().cpu().double() - before[n]
+        assert (upd - upd_ref).abs().max().item() < 2e-7, n                     # |update| <= lr = 1e-4
+    # the module really holds the updated weights and derived caches follow them
+    name0 = next(iter(ts.model.names))
+    assert torch.equal(dict(pred.named_parameters())[name0].data, ts.model.names[name0].data)
+    ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))

@@ -224,6 +224,104 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// ---- frozen SAVi decoder, backward w.r.t. the slots (image loss of the predictor training step) ----
+// Tail (SAVi.py:251-255): img = sum_k rgb_k * m_k, m = softmax_k(alpha).  Given dimg (F,3,H,W):
+//   d rgb_k = dimg * m_k;  d m_k = <dimg, rgb_k>;  d alpha_k = m_k * (d m_k - sum_j m_j d m_j)
+// written as dy (F*K, H, W, 4) NHWC = gradient of the 3x3 tail conv's output.  Thread = (f, pixel).
+__global__ __launch_bounds__(256) void dec_tail_grad_kernel(const float* __restrict__ dimg, const float* __restrict__ recons,
+                                                            const float* __restrict__ masks, float* __restrict__ dy,
+                                                            int F, int K, int HW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)F * HW) return;
+    const int f = (int)(i / HW), p = (int)(i % HW);
+    const float d0 = dimg[((size_t)f * 3 + 0) * HW + p], d1 = dimg[((size_t)f * 3 + 1) * HW + p],
+                d2 = dimg[((size_t)f * 3 + 2) * HW + p];
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float* r = recons + ((size_t)f * K + k) * 3 * HW + p;
+        const float m = masks[((size_t)f * K + k) * HW + p];
+        s += m * (d0 * r[0] + d1 * r[HW] + d2 * r[2 * HW]);
+    }
+    for (int k = 0; k < K; ++k) {
+        const float* r = recons + ((size_t)f * K + k) * 3 * HW + p;
+        const float m = masks[((size_t)f * K + k) * HW + p];
+        const float dm = d0 * r[0] + d1 * r[HW] + d2 * r[2 * HW];
+        f32x4 o = {d0 * m, d1 * m, d2 * m, m * (dm - s)};
+        *reinterpret_cast<f32x4*>(dy + (((size_t)f * K + k) * HW + p) * 4) = o;
+    }
+}
+
+// dx[n,y,x,ci] = relu'(act[n,y,x,ci]) * sum_{co<4, taps} w[co,ci,ty,tx] * dy[n, y+1-ty, x+1-tx, co]
+// (transposed 3x3 conv 4 -> C of the tail, fused with the ReLU mask of the layer that fed it).
+// Thread = (pixel, 4 input channels); w (4, C, 3, 3) nn.Conv2d layout.
+__global__ __launch_bounds__(256) void conv3x3_t4_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         const float* __restrict__ act, float* __restrict__ dx,
+                                                         long npix_total, int H, int W, int C) {
+    const int cq = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total * cq) return;
+    const long pix = i / cq;
+    const int c4 = (int)(i % cq) * 4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int yy = y + 1 - ty, xx = x + 1 - tx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix + (long)(yy - y) * W + (xx - x)) * 4);
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += w[((size_t)co * C + c4 + u) * 9 + ty * 3 + tx] * g[co];
+        }
+    const f32x4 a = *reinterpret_cast<const f32x4*>(act + pix * C + c4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = a[u] > 0.f ? acc[u] : 0.f;
+    *reinterpret_cast<f32x4*>(dx + pix * C + c4) = acc;
+}
+
+// Collapsed decoder layer 0: x_in[n,p,:] = relu(cpos[p,:] + S[n, cls(p), :]).
+// dS[n, cls, c] = sum over the pixels p of class cls of g[n,p,c] * (x_in > 0).  One workgroup per
+// slot image; thread = (16 pixel lanes) x (16 channel quads); the 3600 interior pixels (class 12)
+// accumulate in registers, border pixels through LDS atomics.
+__device__ __forceinline__ int border_cls(int p, int n) { return p < 2 ? p : (p >= n - 2 ? 4 - (n - 1 - p) : 2); }
+
+__global__ __launch_bounds__(256) void dec_class_reduce_kernel(const float* __restrict__ g, const float* __restrict__ cpos,
+                                                               const float* __restrict__ S, float* __restrict__ dS,
+                                                               int H, int W) {
+    constexpr int C = 64;
+    __shared__ float acc_s[25 * C];
+    const int n = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < 25 * C; i += 256) acc_s[i] = 0.f;
+    __syncthreads();
+    const int c4 = (t & 15) * 4, pl = t >> 4;
+    const float* Sn = S + (size_t)n * 25 * C;
+    const float* gn = g + (size_t)n * H * W * C;
+    f32x4 inner = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 s_in = *reinterpret_cast<const f32x4*>(Sn + 12 * C + c4);
+    for (int p = pl; p < H * W; p += 16) {
+        const int y = p / W, x = p % W;
+        const int cls = border_cls(y, H) * 5 + border_cls(x, W);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gn + (size_t)p * C + c4);
+        const f32x4 cp = *reinterpret_cast<const f32x4*>(cpos + (size_t)p * C + c4);
+        if (cls == 12) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) inner[u] += (cp[u] + s_in[u]) > 0.f ? gv[u] : 0.f;
+        } else {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(Sn + cls * C + c4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (cp[u] + sv[u] > 0.f) atomicAdd(&acc_s[cls * C + c4 + u], gv[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) atomicAdd(&acc_s[12 * C + c4 + u], inner[u]);
+    __syncthreads();
+    for (int i = t; i < 25 * C; i += 256) dS[(size_t)n * 25 * C + i] = acc_s[i];
+}
+
 inline unsigned blocks256(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -322,5 +420,35 @@ extern "C" int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
                        n, lr, beta1, beta2, eps, bc1, bc2, gscale);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_tail_grad_f32(const float* dimg, const float* recons, const float* masks, float* dy,
+                                       int F, int K, int H, int W, void* stream) {
+    TOCVP_CHECK_ARG(dimg && recons && masks && dy && F >= 0 && K > 0 && H > 0 && W > 0);
+    if (F == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(dec_tail_grad_kernel, dim3(blocks256((long)F * H * W)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dimg, recons, masks, dy, F, K, H * W);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float* act, float* dx, int nimg,
+                                    int H, int W, int C, void* stream) {
+    TOCVP_CHECK_ARG(dy && w && act && dx && nimg >= 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+    if (!tocvp_aligned16(dy) || !tocvp_aligned16(act) || !tocvp_aligned16(dx)) return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    const long npix = (long)nimg * H * W;
+    hipLaunchKernelGGL(conv3x3_t4_kernel, dim3(blocks256(npix * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, w, act, dx, npix, H, W, C);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_class_reduce_f32(const float* g, const float* cpos, const float* S, float* dS,
+                                          int nimg, int H, int W, int C, void* stream) {
+    TOCVP_CHECK_ARG(g && cpos && S && dS && nimg >= 0 && H >= 4 && W >= 4 && C == 64);
+    if (!tocvp_aligned16(g) || !tocvp_aligned16(cpos) || !tocvp_aligned16(S)) return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(dec_class_reduce_kernel, dim3(nimg), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+                       cpos, S, dS, H, W);
     return tocvp_launch_status();
 }

@@ -43,10 +43,12 @@ class TrainablePredictor:
         self.precision = precision
         self.vars = {}
         self.names = {}
+        self.params = {}
         for name, p in wrapper.named_parameters():
             v = ag.Var(p.data, requires_grad=True, name=name)
             self.vars[id(p)] = v
             self.names[name] = v
+            self.params[name] = p
 
     def V(self, param):
         return self.vars[id(param)]
@@ -54,6 +56,17 @@ class TrainablePredictor:
     def zero_grad(self):
         for v in self.vars.values():
             v.grad = None
+
+    def mark_updated(self):
+        """ the optimiser kernel wrote the weights through raw pointers: bump the tensor version counters so
+        that every cache derived from a weight (operand planes, fused / packed copies) is rebuilt """
+        bump = getattr(torch._C, "_increment_version", None)
+        for name, p in self.params.items():
+            for t in (p, self.names[name].data):
+                if bump is not None:
+                    bump(t)
+                else:
+                    t.add_(0)
 
     # ---------------------------------------------------------------------------------------
     def _lin(self, tape, x, mod, act=K.ACT_NONE):
