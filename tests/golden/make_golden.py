@@ -313,6 +313,49 @@ def t5_fixtures(out_dir):
     print("t5_encoder:", out.shape, float(out.abs().max()))
 
 
+def train_fixtures(out_dir):
+    """
+    Predictor training step of the reference (04_train_predictor.py:57-108 without the optimiser):
+    frozen SAVi decomp (no grad) -> PredictorWrapper rollout -> SAVi.decode -> nn.MSELoss on images +
+    nn.MSELoss on slots (lib/loss.py:150-191, weights 1 / 1, CONFIG.py:42-51), loss.backward() through
+    torch.autograd, with dropout inactive (eval-mode modules, gradients still flow).  K=7, B=2,
+    1 seed + 2 preds.  Stored: the two losses, the L2 norm of every
+    parameter gradient, and four gradients in full.
+    """
+    P = 2
+    savi, wrapper = build_reference(num_slots=7, num_context=1, num_preds=P)
+    wrapper.eval()      # deterministic: the text encoder's dropout (p = 0.1, text_encoders.py:36,64,107) is off
+    for p_ in savi.parameters():
+        p_.requires_grad_(False)
+    videos = synth.synth_videos(2, 1 + P, seed=0)
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    B, L, C, H, W = videos.shape
+    with torch.no_grad(), FixedNoise(noise):
+        hist = savi(mode="decomp", x=videos, num_imgs=1 + P, decode=False,
+                    caption_tokens=tokens, caption_lengths=lengths)["slot_history"]
+    pred_slots = wrapper(hist, caption_tokens=tokens, caption_lengths=lengths)
+    dec = savi(mode="decode", slots=pred_slots.clone().reshape(B * P, 7, 128))
+    pred_imgs = dec["recons_imgs"].view(B, P, C, H, W)
+    mse = torch.nn.MSELoss()
+    l_img = mse(pred_imgs, videos[:, 1:1 + P])
+    l_slot = mse(pred_slots, hist[:, 1:1 + P])
+    (l_img + l_slot).backward()
+    names, norms, full = [], [], {}
+    keep = ("predictor.mlp_out.weight", "predictor.pe.pe", "predictor.predictor.0.attn.q.weight",
+            "predictor.text_encoder.position_embedding.weight")
+    for name, p_ in wrapper.named_parameters():
+        g = torch.zeros_like(p_) if p_.grad is None else p_.grad
+        names.append(name)
+        norms.append(float(g.norm()))
+        if name in keep:                             # large matrices: every 4th row / column
+            full["grad::" + name] = (g[::4, ::4] if g.dim() == 2 and g.numel() > 40000 else g).detach().numpy()
+    np.savez(os.path.join(out_dir, "train_c5.npz"), loss_img=l_img.item(), loss_slot=l_slot.item(),
+             names=np.array(names), grad_norms=np.array(norms, dtype=np.float64),
+             pred_slots=pred_slots.detach().numpy(), **full)
+    print("train_c5: losses", l_img.item(), l_slot.item(), "params", len(names), "kept", sorted(full))
+
+
 @torch.no_grad()
 def manifest(out_dir):
     """ state_dict key/shape manifest = the checkpoint-layout contract. """
@@ -328,7 +371,7 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur", "t5"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur", "t5", "train"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -341,3 +384,5 @@ if __name__ == "__main__":
         dinosaur_fixtures(HERE)
     if "t5" in what:
         t5_fixtures(HERE)
+    if "train" in what:
+        train_fixtures(HERE)

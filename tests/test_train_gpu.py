@@ -244,3 +244,78 @@ def test_training_step_gradients_with_image_loss_match_oracle_autograd():
     name0 = next(iter(ts.model.names))
     assert torch.equal(dict(pred.named_parameters())[name0].data, ts.model.names[name0].data)
     ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+
+
+def _build_step(Ks=7, P=2):
+    from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
+    from textocvp_amd.train.step import PredictorTrainStep
+    exp = default_exp_params(num_slots=Ks, num_context=1, num_preds=P)
+    savi, pred = setup_model(exp["model"]).eval(), setup_predictor(exp)
+    synth.fill_module_(savi, prefix="savi.")
+    synth.fill_module_(pred, prefix="pred.")
+    ts = PredictorTrainStep(savi.to(DEV), pred.to(DEV), lr=1e-4, clip=0.05, warmup_steps=0)
+    videos = synth.synth_videos(2, 1 + P, seed=0)
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(2, Ks, 128, seed=1)
+    return ts, videos, tokens, lengths, noise
+
+
+def test_training_step_against_reference_golden():
+    """ losses and gradients of the reference's own training step (torch.autograd on the reference
+    modules, tests/golden/train_c5.npz) """
+    from conftest import load_golden
+    g = load_golden("train_c5.npz")
+    ts, videos, tokens, lengths, noise = _build_step()
+    losses = ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+    assert abs(losses["pred_img_mse"] - float(g["loss_img"])) < 2e-4 * float(g["loss_img"])
+    assert abs(losses["pred_slot_mse"] - float(g["loss_slot"])) < 2e-4 * float(g["loss_slot"])
+    worst = 0.0
+    for name, ref_norm in zip(g["names"], g["grad_norms"]):
+        v = ts.model.names[str(name)]
+        norm = 0.0 if v.grad is None else float(v.grad.norm())
+        e = abs(norm - float(ref_norm)) / max(float(ref_norm), 1e-8)
+        worst = max(worst, e if float(ref_norm) > 1e-7 else 0.0)
+        assert e < 5e-3 or abs(norm - float(ref_norm)) < 1e-8, (str(name), norm, float(ref_norm))
+    for key in g:
+        if key.startswith("grad::"):
+            grad = ts.model.names[key[6:]].grad
+            if grad.dim() == 2 and grad.numel() > 40000:
+                grad = grad[::4, ::4]
+            ref = torch.from_numpy(g[key])
+            assert rel_err(grad.reshape(ref.shape), ref) < 5e-3, key
+    print(f"vs reference golden: worst gradient-norm error {worst:.2e}")
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ts, videos, tokens, lengths, noise = _build_step()
+    sl = slice(rank, rank + 1)                                  # one sequence per rank, same padded captions
+    ts.loss_and_grads(videos[sl].to(DEV), tokens[sl].to(DEV), lengths[sl].to(DEV), init_noise=noise[sl].to(DEV))
+    ts.all_reduce_grads()
+    if rank == 0:
+        torch.save({n: v.grad.cpu() for n, v in ts.model.names.items() if v.grad is not None},
+                   os.path.join(out_dir, "avg.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch(tmp_path):
+    """ data-parallel step: two ranks (gloo, both on this GPU) with one sequence each + the flat
+    all-reduce == the gradient of the two-sequence batch (MSE means over equal shares) """
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    avg = torch.load(tmp_path / "avg.pt")
+    ts, videos, tokens, lengths, noise = _build_step()
+    ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+    for name, v in ts.model.names.items():
+        if v.grad is None:
+            continue
+        assert rel_err(avg[name], v.grad.cpu()) < 2e-4, name
