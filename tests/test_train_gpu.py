@@ -28,13 +28,15 @@ def _ag():
     return autograd
 
 
+@pytest.mark.parametrize("rows", [100, 512])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
-def test_linear_backward(act):
+def test_linear_backward(act, rows):
+    """ rows = 100: generic fp32 batched GEMM; rows = 512 (M = 1536): the bf16x6 split GEMM on transposed copies """
     ag = _ag()
     from textocvp_amd import kernels as K
-    M, N, Kd = 300, 192, 128
-    x, w, b = rnd("lx", (3, 100, Kd)), rnd("lw", (N, Kd), "uniform", Kd ** -0.5), rnd("lb", (N,), "uniform", 0.1)
-    gy = rnd("lg", (3, 100, N))
+    N, Kd = 192, 128
+    x, w, b = rnd("lx", (3, rows, Kd)), rnd("lw", (N, Kd), "uniform", Kd ** -0.5), rnd("lb", (N,), "uniform", 0.1)
+    gy = rnd("lg", (3, rows, N)) * 1e-4                  # small gradients: must not be flushed
     xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
     pre = xr @ wr.t() + br
     y = {"none": pre, "relu": torch.relu(pre), "gelu": F.gelu(pre)}[act]
@@ -49,6 +51,12 @@ def test_linear_backward(act):
     assert rel_err(X.grad, xr.grad) < 1e-5
     assert rel_err(W.grad, wr.grad) < 1e-5
     assert rel_err(B.grad, br.grad) < 1e-5
+    # a second use of the same weight accumulates into the existing gradient
+    tape = ag.Tape()
+    Y2 = ag.linear(tape, X, W, B, act=code)
+    Y2.grad = gy.to(DEV)
+    tape.backward()
+    assert rel_err(W.grad, 2 * wr.grad) < 1e-5 and rel_err(B.grad, 2 * br.grad) < 1e-5
 
 
 def test_layer_norm_backward():

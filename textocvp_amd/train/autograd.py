@@ -88,7 +88,7 @@ def bmm(A, B, C, M, N, Kd, lda, ldb, ldc, transA=False, transB=False, batch=(1, 
 def colsum(x2, out=None, acc=False):
     """ x2 (rows, cols) contiguous -> (cols,) column sums, deterministic two-stage """
     rows, cols = x2.shape
-    chunk = 512
+    chunk = 32 if rows >= 2048 else max(1, (rows + 63) // 64)      # enough workgroups to fill the chip
     nch = (rows + chunk - 1) // chunk
     part = torch.empty((nch, cols), device=x2.device, dtype=torch.float32)
     K._check(_L().tocvp_colsum_partial_f32(_p(x2), _p(part), rows, cols, cols, chunk, _s()),
@@ -129,8 +129,18 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
             g = gg
         M = g.shape[0]
         x2 = x.data.reshape(M, Kd)
+        # Large, aligned shapes run on the split-operand GEMM of the forward pass (bf16x6: fp32-class and,
+        # unlike the fp16 planes, with the fp32 exponent range that small gradients need); the operands
+        # it wants transposed are copied (data movement).  Everything else takes the generic fp32 kernel.
+        fast = M >= 1024 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
         if W.requires_grad:                               # dW (N, K) = g^T (N, M) x (M, K)
-            if W.grad is None:
+            if fast:
+                gT, xT = g.t().contiguous(), x2.t().contiguous()
+                if W.grad is None:
+                    W.grad = K.linear(gT, xT, precision="bf16x6")
+                else:
+                    K.linear(gT, xT, residual=W.grad, out=W.grad, precision="bf16x6")
+            elif W.grad is None:
                 W.grad = torch.empty_like(W.data)
                 bmm(g, x2, W.grad, N, Kd, M, N, Kd, Kd, transA=True)
             else:
@@ -141,8 +151,11 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
             else:
                 colsum(g, out=b.grad, acc=True)
         if x.requires_grad:                               # dx (M, K) = g (M, N) W (N, K)
-            dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
-            bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
+            if fast:
+                dx = K.linear(g, W.data.t().contiguous(), precision="bf16x6")
+            else:
+                dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
+                bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
             accumulate(x, dx)
     tape.record(backward)
     return out
