@@ -253,10 +253,17 @@ __global__ __launch_bounds__(256) void dec_tail_grad_kernel(const float* __restr
 
 // dx[n,y,x,ci] = relu'(act[n,y,x,ci]) * sum_{co<4, taps} w[co,ci,ty,tx] * dy[n, y+1-ty, x+1-tx, co]
 // (transposed 3x3 conv 4 -> C of the tail, fused with the ReLU mask of the layer that fed it).
-// Thread = (pixel, 4 input channels); w (4, C, 3, 3) nn.Conv2d layout.
+// Thread = (pixel, 4 input channels); w (4, C, 3, 3) nn.Conv2d layout, staged once per workgroup in LDS
+// as [tap][co][C] so that a thread reads its 4 channels of one (tap, co) with one 16-byte access.
 __global__ __launch_bounds__(256) void conv3x3_t4_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                          const float* __restrict__ act, float* __restrict__ dx,
                                                          long npix_total, int H, int W, int C) {
+    __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 64];
+    for (int i = threadIdx.x; i < 9 * 4 * C; i += 256) {
+        const int c = i % C, co = (i / C) & 3, tap = i / (4 * C);
+        ws[i] = w[((size_t)co * C + c) * 9 + tap];
+    }
+    __syncthreads();
     const int cq = C / 4;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix_total * cq) return;
@@ -272,9 +279,10 @@ __global__ __launch_bounds__(256) void conv3x3_t4_kernel(const float* __restrict
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
             const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix + (long)(yy - y) * W + (xx - x)) * 4);
 #pragma unroll
-            for (int co = 0; co < 4; ++co)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] += w[((size_t)co * C + c4 + u) * 9 + ty * 3 + tx] * g[co];
+            for (int co = 0; co < 4; ++co) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((ty * 3 + tx) * 4 + co) * C + c4);
+                acc += wv * g[co];
+            }
         }
     const f32x4 a = *reinterpret_cast<const f32x4*>(act + pix * C + c4);
 #pragma unroll
@@ -434,7 +442,7 @@ extern "C" int tocvp_dec_tail_grad_f32(const float* dimg, const float* recons, c
 
 extern "C" int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float* act, float* dx, int nimg,
                                     int H, int W, int C, void* stream) {
-    TOCVP_CHECK_ARG(dy && w && act && dx && nimg >= 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+    TOCVP_CHECK_ARG(dy && w && act && dx && nimg >= 0 && H > 0 && W > 0 && C > 0 && C <= 64 && (C & 3) == 0);
     if (!tocvp_aligned16(dy) || !tocvp_aligned16(act) || !tocvp_aligned16(dx)) return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     const long npix = (long)nimg * H * W;
