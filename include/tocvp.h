@@ -342,6 +342,9 @@ int tocvp_softmax_bwd_f32(const float* p, const float* dp, float* ds, int rows, 
 /* y = act(x) and dx = dy * act'(x) for TOCVP_ACT_RELU / TOCVP_ACT_GELU (for ReLU x may be the output) */
 int tocvp_act_f32(const float* x, float* y, long n, int act, void* stream);
 int tocvp_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);
+/* nn.Dropout (text encoder, text_encoders.py:36,64,107 and its nn.TransformerEncoderLayer): the caller
+ * supplies the uniform sample r in [0,1); y = r >= p ? x / (1 - p) : 0; backward = same call on the gradient */
+int tocvp_dropout_f32(const float* x, const float* r, float* y, long n, float p, void* stream);
 /* y = a * x + b * y (gradient accumulation, residual adds) */
 int tocvp_axpby_f32(const float* x, float* y, long n, float a, float b, void* stream);
 /* partial[chunk, c] = sum of x[r, c] over the rows of the chunk (bias / parameter gradients; run once

@@ -164,7 +164,7 @@ def test_predictor_rollout_gradients_match_oracle_autograd():
     ref_loss.backward()
 
     pred = pred.to(DEV)
-    tp = TrainablePredictor(pred)
+    tp = TrainablePredictor(pred, text_dropout=0.0)
     tape = ag.Tape()
     preds = tp.rollout(tape, hist.to(DEV), tokens.to(DEV), lengths.to(DEV), P)
     stacked = ag.stack_frames(tape, preds)
@@ -215,7 +215,7 @@ def test_training_step_gradients_with_image_loss_match_oracle_autograd():
     (l_img + l_slot).backward()
 
     savi, pred = savi.to(DEV), pred.to(DEV)
-    ts = PredictorTrainStep(savi, pred, lr=1e-4, clip=0.05, warmup_steps=0)
+    ts = PredictorTrainStep(savi, pred, lr=1e-4, clip=0.05, warmup_steps=0, text_dropout=0.0)
     losses = ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
     assert abs(losses["pred_img_mse"] - l_img.item()) < 2e-4 * abs(l_img.item())
     assert abs(losses["pred_slot_mse"] - l_slot.item()) < 2e-4 * abs(l_slot.item())
@@ -261,7 +261,7 @@ def _build_step(Ks=7, P=2):
     savi, pred = setup_model(exp["model"]).eval(), setup_predictor(exp)
     synth.fill_module_(savi, prefix="savi.")
     synth.fill_module_(pred, prefix="pred.")
-    ts = PredictorTrainStep(savi.to(DEV), pred.to(DEV), lr=1e-4, clip=0.05, warmup_steps=0)
+    ts = PredictorTrainStep(savi.to(DEV), pred.to(DEV), lr=1e-4, clip=0.05, warmup_steps=0, text_dropout=0.0)
     videos = synth.synth_videos(2, 1 + P, seed=0)
     tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
     noise = synth.synth_noise(2, Ks, 128, seed=1)
@@ -327,3 +327,66 @@ def test_two_rank_gradient_average_equals_full_batch(tmp_path):
         if v.grad is None:
             continue
         assert rel_err(avg[name], v.grad.cpu()) < 2e-4, name
+
+
+def test_dropout_and_attention_probability_dropout():
+    """ nn.Dropout / nn.MultiheadAttention(dropout=p) in training mode with a shared uniform sample """
+    ag = _ag()
+    p = 0.1
+    x, gy = rnd("dx", (5, 12, 128)), rnd("dgy", (5, 12, 128))
+    r = torch.rand(5, 12, 128, generator=torch.Generator().manual_seed(3))
+    xr = x.double().requires_grad_()
+    y = xr * (r >= p).double() / (1 - p)
+    y.backward(gy.double())
+    tape = ag.Tape()
+    X = ag.Var(x.to(DEV), True)
+    Y = ag.dropout(tape, X, p, sample=r.to(DEV))
+    Y.grad = gy.to(DEV)
+    tape.backward()
+    assert rel_err(Y.data, y) < 1e-6 and rel_err(X.grad, xr.grad) < 1e-6
+    kept = (Y.data != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.02
+    # attention with dropout on the probabilities, key padding
+    B, H, T, E = 3, 4, 12, 128
+    q, k, v, go = rnd("uq", (B, T, E)), rnd("uk", (B, T, E)), rnd("uv", (B, T, E)), rnd("ugo", (B, T, E))
+    lens = [12, 5, 9]
+    rs = torch.rand(B, H, T, T, generator=torch.Generator().manual_seed(4))
+    scale = (E // H) ** -0.5
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+
+    def heads(t):
+        return t.reshape(B, T, H, E // H).transpose(1, 2)
+    sc = heads(qr) @ heads(kr).transpose(-1, -2) * scale
+    mask = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
+    pr = torch.softmax(sc.masked_fill(mask[:, None, None, :], float("-inf")), -1)
+    o = ((pr * (rs >= p).double() / (1 - p)) @ heads(vr)).transpose(1, 2).reshape(B, T, E)
+    o.backward(go.double())
+    tape = ag.Tape()
+    Q, Kv, V = (ag.Var(t.to(DEV), True) for t in (q, k, v))
+    O = ag.attention_unfused(tape, Q, Kv, V, H, scale, key_len=torch.tensor(lens, dtype=torch.int32, device=DEV),
+                             p_drop=p, sample=rs.to(DEV))
+    O.grad = go.to(DEV)
+    tape.backward()
+    assert rel_err(O.data, o) < 1e-5
+    for got, ref in ((Q, qr), (Kv, kr), (V, vr)):
+        assert rel_err(got.grad, ref.grad) < 2e-5
+
+
+def test_training_step_with_text_dropout_is_reproducible_and_close():
+    """ default step = the reference's training mode (caption-encoder dropout 0.1): same generator seed ->
+    same gradients; the loss stays near the deterministic one """
+    from textocvp_amd.train.step import PredictorTrainStep
+    ts0, videos, tokens, lengths, noise = _build_step()
+    base = ts0.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+    outs = []
+    for _ in range(2):
+        g = torch.Generator(device=DEV).manual_seed(11)
+        ts = PredictorTrainStep(ts0.savi, ts0.wrapper, lr=1e-4, warmup_steps=0, generator=g)
+        assert ts.model.text_dropout == pytest.approx(0.1)
+        losses = ts.loss_and_grads(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+        outs.append((losses, {n: v.grad.clone() for n, v in ts.model.names.items() if v.grad is not None}))
+    assert outs[0][0] == outs[1][0]
+    for n in outs[0][1]:      # same dropout masks; the LDS / global float atomics of two kernels reorder sums
+        assert rel_err(outs[0][1][n], outs[1][1][n].cpu()) < 1e-5, n
+    assert abs(outs[0][0]["loss"] - base["loss"]) < 0.05 * base["loss"]
+    assert outs[0][0]["loss"] != base["loss"]

@@ -76,6 +76,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     dx[i] = act == 1 ? (v > 0.f ? dy[i] : 0.f) : dy[i] * gelu_grad(v);
 }
 
+// nn.Dropout with a caller-supplied uniform sample r in [0,1): y = r >= p ? x / (1 - p) : 0.  The same r
+// applied to a gradient is the backward pass.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                      float* __restrict__ y, long n, float p, float inv_keep) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    y[i] = r[i] >= p ? x[i] * inv_keep : 0.f;
+}
+
 // y = a * x + b * y
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                                                     float a, float b) {
@@ -458,5 +467,13 @@ extern "C" int tocvp_dec_class_reduce_f32(const float* g, const float* cpos, con
     if (nimg == 0) return TOCVP_OK;
     hipLaunchKernelGGL(dec_class_reduce_kernel, dim3(nimg), dim3(256), 0, static_cast<hipStream_t>(stream), g,
                        cpos, S, dS, H, W);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dropout_f32(const float* x, const float* r, float* y, long n, float p, void* stream) {
+    TOCVP_CHECK_ARG(x && r && y && n >= 0 && p >= 0.f && p < 1.f);
+    if (n == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, r, y, n,
+                       p, 1.f / (1.f - p));
     return tocvp_launch_status();
 }

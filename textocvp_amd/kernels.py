@@ -123,6 +123,8 @@ _SIGNATURES = {
                                      ctypes.c_void_p]),
     "tocvp_act_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
                                          ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_dropout_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                         ctypes.c_float, ctypes.c_void_p]),
     "tocvp_axpby_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_void_p]),
     "tocvp_colsum_partial_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

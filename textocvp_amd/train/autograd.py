@@ -15,8 +15,9 @@ import torch
 
 from .. import kernels as K
 
-__all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "add", "activation", "add_position_rows",
-           "stack_frames", "take_frame", "embedding", "mask_rows", "mse", "accumulate", "bmm"]
+__all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "attention_unfused", "dropout", "add",
+           "activation", "add_position_rows", "stack_frames", "take_frame", "embedding", "mask_rows", "mse",
+           "accumulate", "bmm"]
 
 _L = K.lib
 
@@ -240,6 +241,80 @@ def attention(tape, q, k, v, heads, scale, key_len=None):
                 bmm(dP, k.data, dQ, Tq, dh, Tk, Tk, E, E, batch=hb, sA=sS, sB=sK, sC=sQ)
                 accumulate(q, dQ)
             if k.requires_grad:                           # dK = dS^T Q
+                dK = torch.empty_like(k.data)
+                bmm(dP, q.data, dK, Tk, dh, Tq, Tk, E, E, transA=True, batch=hb, sA=sS, sB=sQ, sC=sK)
+                accumulate(k, dK)
+    tape.record(backward)
+    return out
+
+
+def _dropout_raw(x, r, p):
+    y = torch.empty_like(x)
+    K._check(_L().tocvp_dropout_f32(_p(x), _p(r), _p(y), x.numel(), float(p), _s()), "tocvp_dropout_f32")
+    return y
+
+
+def dropout(tape, x, p, generator=None, sample=None):
+    """ nn.Dropout(p) in training mode; ``sample`` (uniform [0,1), same shape) overrides the generator """
+    if p <= 0.0:
+        return x
+    r = sample if sample is not None else torch.rand(x.data.shape, device=x.data.device, generator=generator)
+    out = Var(_dropout_raw(x.data, r, p), x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is not None:
+                accumulate(x, _dropout_raw(out.grad, r, p))
+        tape.record(backward)
+    return out
+
+
+def attention_unfused(tape, q, k, v, heads, scale, key_len=None, p_drop=0.0, generator=None, sample=None):
+    """
+    Attention with dropout on the probabilities (nn.MultiheadAttention in training mode): the scores are
+    materialised (B, H, Tq, Tk), so this is for short sequences (the caption encoder).
+    """
+    B, Tq, E = q.data.shape
+    Tk = k.data.shape[1]
+    dh = E // heads
+    dev = q.data.device
+    hb = (B, heads)
+    sQ, sK = (Tq * E, dh), (Tk * E, dh)
+    sS = (heads * Tq * Tk, Tq * Tk)
+    P = torch.empty((B, heads, Tq, Tk), device=dev, dtype=torch.float32)
+    bmm(q.data, k.data, P, Tq, Tk, dh, E, E, Tk, transB=True, batch=hb, sA=sQ, sB=sK, sC=sS)
+    K._check(_L().tocvp_softmax_rows_f32(_p(P), _p(P), B * heads * Tq, Tk, float(scale), _p(key_len),
+                                         heads * Tq, _s()), "tocvp_softmax_rows_f32")
+    r = None
+    Pd = P
+    if p_drop > 0.0:
+        r = sample if sample is not None else torch.rand(P.shape, device=dev, generator=generator)
+        Pd = _dropout_raw(P, r, p_drop)
+    o = torch.empty((B, Tq, E), device=dev, dtype=torch.float32)
+    bmm(Pd, v.data, o, Tq, dh, Tk, Tk, E, E, batch=hb, sA=sS, sB=sK, sC=sQ)
+    out = Var(o, q.requires_grad or k.requires_grad or v.requires_grad)
+    if not out.requires_grad:
+        return out
+
+    def backward():
+        if out.grad is None:
+            return
+        dO = out.grad
+        if v.requires_grad:
+            dV = torch.empty_like(v.data)
+            bmm(Pd, dO, dV, Tk, dh, Tq, Tk, E, E, transA=True, batch=hb, sA=sS, sB=sQ, sC=sK)
+            accumulate(v, dV)
+        if q.requires_grad or k.requires_grad:
+            dP = torch.empty_like(P)
+            bmm(dO, v.data, dP, Tq, Tk, dh, E, E, Tk, transB=True, batch=hb, sA=sQ, sB=sK, sC=sS)
+            if r is not None:
+                dP = _dropout_raw(dP, r, p_drop)
+            K._check(_L().tocvp_softmax_bwd_f32(_p(P), _p(dP), _p(dP), B * heads * Tq, Tk, float(scale), _s()),
+                     "tocvp_softmax_bwd_f32")
+            if q.requires_grad:
+                dQ = torch.empty_like(q.data)
+                bmm(dP, k.data, dQ, Tq, dh, Tk, Tk, E, E, batch=hb, sA=sS, sB=sK, sC=sQ)
+                accumulate(q, dQ)
+            if k.requires_grad:
                 dK = torch.empty_like(k.data)
                 bmm(dP, q.data, dK, Tk, dh, Tq, Tk, E, E, transA=True, batch=hb, sA=sS, sB=sQ, sC=sK)
                 accumulate(k, dK)

@@ -35,12 +35,19 @@ def _split_last(tape, x, n):
 
 
 class TrainablePredictor:
-    def __init__(self, wrapper, precision="f16x3"):
+    def __init__(self, wrapper, precision="f16x3", text_dropout=None, generator=None):
+        """
+        text_dropout: dropout probability of the caption encoder in training (None = the module's own p,
+        0.1 in the reference, text_encoders.py:36); 0 gives the deterministic (eval-mode) gradient.
+        generator: torch.Generator on the device for the dropout samples.
+        """
         self.wrapper = wrapper
         self.pred = wrapper.predictor
         if type(self.pred).__name__ != "TextOCVP_CustomTF":
             raise NotImplementedError("training step: TextOCVP_CustomTF only (reference config 5)")
         self.precision = precision
+        self.text_dropout = float(self.pred.text_encoder.dropout.p if text_dropout is None else text_dropout)
+        self.generator = generator
         self.vars = {}
         self.names = {}
         self.params = {}
@@ -83,18 +90,26 @@ class TrainablePredictor:
         key_len = lengths.to(device=tokens.device, dtype=torch.int32).contiguous()
         x = ag.embedding(tape, tokens, self.V(te.token_embedding.weight))
         x = ag.add_position_rows(tape, x, self.V(te.position_embedding.weight), list(range(L)))
-        x = self._ln(tape, x, te.layer_norm)
+        pd, gen = self.text_dropout, self.generator
+
+        def drop(t):
+            return ag.dropout(tape, t, pd, generator=gen)
+        x = drop(self._ln(tape, x, te.layer_norm))
         x = ag.mask_rows(tape, x, tokens != 0)
         E = x.data.shape[-1]
         H = te.num_heads
-        for layer in te.transformer.layers:
+        for layer in te.transformer.layers:                       # post-norm nn.TransformerEncoderLayer, GELU
             sa = layer.self_attn
             qkv = ag.linear(tape, x, self.V(sa.in_proj_weight), self.V(sa.in_proj_bias), precision=self.precision)
             q, k, v = _split_last(tape, qkv, 3)
-            a = ag.attention(tape, q, k, v, H, (E // H) ** -0.5, key_len=key_len)
-            x = self._ln(tape, ag.add(tape, self._lin(tape, a, sa.out_proj), x), layer.norm1)
-            h = self._lin(tape, x, layer.linear1, act=K.ACT_GELU)
-            x = self._ln(tape, ag.add(tape, self._lin(tape, h, layer.linear2), x), layer.norm2)
+            if pd > 0.0:
+                a = ag.attention_unfused(tape, q, k, v, H, (E // H) ** -0.5, key_len=key_len, p_drop=pd,
+                                         generator=gen)
+            else:
+                a = ag.attention(tape, q, k, v, H, (E // H) ** -0.5, key_len=key_len)
+            x = self._ln(tape, ag.add(tape, drop(self._lin(tape, a, sa.out_proj)), x), layer.norm1)
+            h = drop(self._lin(tape, x, layer.linear1, act=K.ACT_GELU))
+            x = self._ln(tape, ag.add(tape, drop(self._lin(tape, h, layer.linear2)), x), layer.norm2)
         return self._lin(tape, self._ln(tape, x, te.text_out_projection[0]), te.text_out_projection[1])
 
     def _self_attention(self, tape, x, attn):

@@ -33,9 +33,9 @@ def _s():
 class PredictorTrainStep:
     def __init__(self, savi, wrapper, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, clip=0.05,
                  loss_weights=(1.0, 1.0), warmup_steps=2000, scheduler_steps=1e6, eta_min=1e-7,
-                 process_group=None):
+                 process_group=None, text_dropout=None, generator=None):
         self.savi, self.wrapper = savi.eval(), wrapper
-        self.model = TrainablePredictor(wrapper)
+        self.model = TrainablePredictor(wrapper, text_dropout=text_dropout, generator=generator)
         self.decoder = DecoderLoss(savi)
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.w_img, self.w_slot = loss_weights
