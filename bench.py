@@ -38,8 +38,9 @@ PATH_GFLOP_PER_FRAME = 149.5             # reference algorithm, 
 ARITH = {
     ("fp32", "fp32"): "fp32",
     ("f16f8", "f16x3"): "split operands on the matrix cores, fp32 accumulate / storage: decoder convs f16f8 "
-                        "(f16 hi product + two e4m3 cross products), predictor GEMMs f16x3 (hi/lo fp16 "
-                        "planes, 3 products); encoder, slot attention, softmax, LayerNorm fp32",
+                        "(f16 hi product + two e4m3 cross products), predictor GEMMs and encoder convs / "
+                        "per-pixel GEMMs f16x3 (hi/lo fp16 planes, 3 products); slot attention, attention "
+                        "scores, softmax, LayerNorm exact fp32",
     ("bf16x3", "f16x3"): "split operands on the 16-bit matrix cores (decoder convs bf16x3 = hi/lo bf16 "
                          "planes, predictor GEMMs f16x3 = hi/lo fp16 planes; 3 products each), fp32 "
                          "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",

@@ -47,6 +47,7 @@ class Var:
 class Tape:
     def __init__(self):
         self.nodes = []
+        self.cache = {}          # per-step derived tensors (transposed weights of the backward GEMMs)
 
     def record(self, fn):
         self.nodes.append(fn)
@@ -55,6 +56,7 @@ class Tape:
         for fn in reversed(self.nodes):
             fn()
         self.nodes = []
+        self.cache = {}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -153,7 +155,10 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
                 colsum(g, out=b.grad, acc=True)
         if x.requires_grad:                               # dx (M, K) = g (M, N) W (N, K)
             if fast:
-                dx = K.linear(g, W.data.t().contiguous(), precision="bf16x6")
+                Wt = tape.cache.get(id(W))          # the same weight is used by every rollout step
+                if Wt is None:
+                    Wt = tape.cache[id(W)] = W.data.t().contiguous()
+                dx = K.linear(g, Wt, precision="bf16x6")
             else:
                 dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
                 bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
