@@ -376,9 +376,13 @@ int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float* act, floa
                          int W, int C, void* stream);
 int tocvp_dec_class_reduce_f32(const float* g, const float* cpos, const float* S, float* dS, int nimg,
                                int H, int W, int C, void* stream);
-/* torch.optim.Adam step (no weight decay / amsgrad) on a flat parameter; g is scaled by gscale first */
-int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                   float beta2, float eps, int step, float gscale, void* stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) on a flat parameter.  The step-dependent scalars are
+ * read from DEVICE memory so that a captured HIP graph of the training step can be replayed:
+ * hyper = {lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t}; gscale (may be NULL) = clipping factor.
+ * tocvp_clip_scale_f32: out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) (clip_grad_norm_), out[1] = norm */
+int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper,
+                   const float* gscale, void* stream);
+int tocvp_clip_scale_f32(const float* sumsq, float max_norm, float* out, void* stream);
 
 #ifdef __cplusplus
 }

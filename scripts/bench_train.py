@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--preds", type=int, default=9)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying "
+                                                         "the captured HIP graphs")
     a = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -52,18 +54,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
     out = None
+    run = ts.step if a.eager else ts.step_graphed
     for _ in range(a.warmup):
-        out = ts.step(videos, tokens, lengths, init_noise=noise)
+        out = run(videos, tokens, lengths, init_noise=noise)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = ts.step(videos, tokens, lengths, init_noise=noise)
+        out = run(videos, tokens, lengths, init_noise=noise)
     fence()
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({
             "metric": "predictor training steps/s", "value": round(a.steps / dt, 3), "unit": "steps/s",
             "ms_per_step": round(1e3 * dt / a.steps, 1), "n_gpus": world,
+            "launch_mode": "eager" if a.eager else "hip graphs (fwd+bwd, optimiser)",
             "sequences_per_s": round(world * a.batch * a.steps / dt, 1),
             "config": {"workload": "configs[4]: TextOCVP_CustomTF training step, frozen SAVi, image + slot MSE, "
                                    "clipped Adam", "batch_per_gpu": a.batch, "num_slots": a.slots,

@@ -429,3 +429,22 @@ def test_rollout_gradients_sliding_window_and_teacher_forcing(buffer, teacher):
         err = (var.grad.detach().cpu().double() - ref).abs() / ref.abs().max()
         assert (err > 5e-3).double().mean().item() < 2e-3, (name, err.max().item())
         assert err.max().item() < 0.2, (name, err.max().item())
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """ three optimisation steps issued launch by launch == one eager step + two replays of the captured
+    HIP graphs (same batches, dropout off): same losses, same weights """
+    res = []
+    for graphed in (False, True):
+        ts, videos, tokens, lengths, noise = _build_step()
+        args = (videos.to(DEV), tokens.to(DEV), lengths.to(DEV))
+        run = ts.step_graphed if graphed else ts.step
+        losses = [run(*args, init_noise=noise.to(DEV)) for _ in range(3)]
+        res.append((losses, {n: v.data.detach().cpu().clone() for n, v in ts.model.names.items()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a["loss"] - b["loss"]) < 1e-5 * abs(a["loss"])
+        assert abs(a["grad_norm"] - b["grad_norm"]) < 1e-4 * a["grad_norm"]
+        assert a["lr"] == b["lr"]
+    assert res[0][0][0]["loss"] != res[0][0][2]["loss"]                       # the weights really moved
+    for n in res[0][1]:
+        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 2e-6, n     # three steps of at most lr = 1e-4

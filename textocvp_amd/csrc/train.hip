@@ -217,20 +217,30 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// torch.optim.Adam (no weight decay, no amsgrad): g' = gscale * g (gradient clipping factor)
+// torch.optim.Adam (no weight decay, no amsgrad).  The step-dependent scalars live in DEVICE memory so
+// that a captured HIP graph of the step can be replayed with new values:
+//   hyper = {lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t},  *gscale = gradient clipping factor.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                                                   float b1, float b2, float eps, float bc1, float bc2,
-                                                   float gscale) {
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ hyper,
+                                                   const float* __restrict__ gscale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i] * gscale;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5];
+    const float gi = g[i] * (gscale ? gscale[0] : 1.f);
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
     p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// clip_grad_norm_: out[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)), out[1] = sqrt(sumsq)
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out) {
+    const float norm = sqrtf(sumsq[0]);
+    out[0] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    out[1] = norm;
 }
 
 // ---- frozen SAVi decoder, backward w.r.t. the slots (image loss of the predictor training step) ----
@@ -430,13 +440,18 @@ extern "C" int tocvp_sqnorm_partial_f32(const float* x, float* partial, int nblo
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                              float beta2, float eps, int step, float gscale, void* stream) {
-    TOCVP_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1);
+extern "C" int tocvp_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper,
+                              const float* gscale, void* stream) {
+    TOCVP_CHECK_ARG(p && g && m && v && hyper && n >= 0);
     if (n == 0) return TOCVP_OK;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks256(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
-                       n, lr, beta1, beta2, eps, bc1, bc2, gscale);
+                       n, hyper, gscale);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_clip_scale_f32(const float* sumsq, float max_norm, float* out, void* stream) {
+    TOCVP_CHECK_ARG(sumsq && out);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), sumsq, max_norm, out);
     return tocvp_launch_status();
 }
 

@@ -148,8 +148,8 @@ _SIGNATURES = {
                                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_void_p]),
     "tocvp_adam_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                      ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                      ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
+                                      ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_clip_scale_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_metrics_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_psnr_ssim_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

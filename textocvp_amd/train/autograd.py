@@ -20,6 +20,7 @@ __all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "attention_unfuse
            "accumulate", "bmm"]
 
 _L = K.lib
+_INDEX_CACHE = {}
 
 
 def _s():
@@ -348,7 +349,10 @@ def add_position_rows(tape, x, table, index):
     """ x (B, w, ...rest) + table[index[pos]] broadcast over B and the inner axes; table (P, E), E = last axis """
     B, w = x.data.shape[:2]
     E = x.data.shape[-1]
-    idx = torch.as_tensor(index, device=x.data.device, dtype=torch.int64)
+    key = (tuple(int(i) for i in index), str(x.data.device))
+    idx = _INDEX_CACHE.get(key)            # host -> device copies are not allowed while a graph is captured
+    if idx is None:
+        idx = _INDEX_CACHE[key] = torch.as_tensor(list(key[0]), device=x.data.device, dtype=torch.int64)
     rows = table.data.index_select(0, idx)                             # (w, E) gather (data movement)
     shape = [1, w] + [1] * (x.data.dim() - 3) + [E]
     addend = rows.reshape(shape).expand_as(x.data).contiguous()
@@ -445,4 +449,4 @@ def mse(tape, pred, target, weight=1.0):
     total = colsum(part.reshape(nblocks, 1))
     if dp is not None:
         tape.record(lambda: accumulate(pred, dp))
-    return total, float(weight) / n
+    return total, float(weight) / n                   # (1,) device tensor (no host sync here) and its scale

@@ -53,8 +53,9 @@ class PredictorTrainStep:
         return self.eta_min + (self.lr - self.eta_min) * (1.0 + math.cos(math.pi * t / self.scheduler_steps)) / 2.0
 
     @torch.no_grad()
-    def loss_and_grads(self, videos, caption_tokens, caption_lengths, **others):
-        """ forward + backward; leaves the gradients in ``self.model.names[*].grad``; returns the losses """
+    def _forward_backward(self, videos, caption_tokens, caption_lengths, others):
+        """ forward + backward on the current stream without any host synchronisation; returns the two
+        sums of squares as (1,) device tensors and their scales """
         wr = self.wrapper
         nc, npred = wr.num_context, wr.num_preds
         B, L, C, H, W = videos.shape
@@ -75,8 +76,13 @@ class PredictorTrainStep:
                                                          grad_scale=2.0 * self.w_img / n_img)
         tape.record(lambda: ag.accumulate(stacked, dslots.reshape(stacked.data.shape)))
         tape.backward()
-        loss_slot = float(sq_slot.item()) * sc_slot
-        loss_img = float(sq_img.item()) * self.w_img / n_img
+        self._grads()                                                       # materialise missing gradients
+        return sq_slot, sc_slot, sq_img, self.w_img / n_img
+
+    def loss_and_grads(self, videos, caption_tokens, caption_lengths, **others):
+        """ forward + backward; leaves the gradients in ``self.model.names[*].grad``; returns the losses """
+        sq_slot, sc_slot, sq_img, sc_img = self._forward_backward(videos, caption_tokens, caption_lengths, others)
+        loss_slot, loss_img = float(sq_slot.item()) * sc_slot, float(sq_img.item()) * sc_img
         return {"loss": loss_slot + loss_img, "pred_slot_mse": loss_slot, "pred_img_mse": loss_img}
 
     # ---------------------------------------------------------------------------------------
@@ -109,7 +115,8 @@ class PredictorTrainStep:
             ag.axpby(flat[off:off + n].contiguous(), v.grad.reshape(-1), 1.0 / world, 0.0)
             off += n
 
-    def grad_norm(self):
+    def _clip_scale(self):
+        """ device side: (2,) tensor {clipping factor, gradient norm} (clip_grad_norm_) """
         vs = self._grads()
         parts = []
         for v in vs:
@@ -119,27 +126,47 @@ class PredictorTrainStep:
             K._check(_L().tocvp_sqnorm_partial_f32(v.grad.data_ptr(), p.data_ptr(), nb, n, _s()),
                      "tocvp_sqnorm_partial_f32")
             parts.append(p)
-        allp = torch.cat(parts)
-        return math.sqrt(float(ag.colsum(allp.reshape(-1, 1)).item()))
+        total = ag.colsum(torch.cat(parts).reshape(-1, 1))
+        out = torch.empty(2, device=total.device, dtype=torch.float32)
+        K._check(_L().tocvp_clip_scale_f32(total.data_ptr(), float(self.clip or 0.0), out.data_ptr(), _s()),
+                 "tocvp_clip_scale_f32")
+        return out
 
-    def apply(self):
-        """ clip_grad_norm_ + Adam on every predictor parameter; returns (grad norm, lr used) """
-        self.iteration += 1
-        norm = self.grad_norm()
-        gscale = 1.0
-        if self.clip is not None:
-            gscale = min(1.0, self.clip / (norm + 1e-6))
-        lr = self.lr_at(self.iteration)
+    def grad_norm(self):
+        return float(self._clip_scale()[1].item())
+
+    def _hyper(self, it):
+        b1, b2 = self.betas
+        return [self.lr_at(it), b1, b2, self.eps, 1.0 - b1 ** it, 1.0 - b2 ** it]
+
+    def _optimizer_kernels(self):
+        """ clip factor + Adam on every parameter, reading the step scalars from ``self._hyper_dev`` """
+        clipn = self._clip_scale()
         for v in self._grads():
             st = self.state.get(id(v))
             if st is None:
                 st = (torch.zeros_like(v.data), torch.zeros_like(v.data))
                 self.state[id(v)] = st
             K._check(_L().tocvp_adam_f32(v.data.data_ptr(), v.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
-                                         v.data.numel(), float(lr), float(self.betas[0]), float(self.betas[1]),
-                                         float(self.eps), self.iteration, float(gscale), _s()), "tocvp_adam_f32")
+                                         v.data.numel(), self._hyper_dev.data_ptr(), clipn.data_ptr(), _s()),
+                     "tocvp_adam_f32")
+        return clipn
+
+    def _set_hyper(self):
+        self.iteration += 1
+        host = torch.tensor(self._hyper(self.iteration), dtype=torch.float32)
+        if getattr(self, "_hyper_dev", None) is None:
+            self._hyper_dev = host.to(next(iter(self.model.names.values())).data.device)
+        else:
+            self._hyper_dev.copy_(host)
+        return float(host[0])
+
+    def apply(self):
+        """ clip_grad_norm_ + Adam on every predictor parameter; returns (grad norm, lr used) """
+        lr = self._set_hyper()
+        clipn = self._optimizer_kernels()
         self.model.mark_updated()
-        return norm, lr
+        return float(clipn[1].item()), lr
 
     def step(self, videos, caption_tokens, caption_lengths, **others):
         losses = self.loss_and_grads(videos, caption_tokens, caption_lengths, **others)
@@ -147,3 +174,46 @@ class PredictorTrainStep:
         norm, lr = self.apply()
         losses.update(grad_norm=norm, lr=lr)
         return losses
+
+    # ---------------------------------------------------------------------------------------
+    def step_graphed(self, videos, caption_tokens, caption_lengths, **others):
+        """
+        Same step replayed from two captured HIP graphs (forward + backward; clipping + Adam), with the
+        gradient all-reduce between them.  The step issues ~20-35 thousand small launches and is bound by
+        the host otherwise.  Shapes must stay fixed; the first call runs one eager step (fills every
+        cache and allocation) and captures, later calls copy the batch into the static inputs and replay.
+        Dropout samples come from torch's graph-safe generator state, so every replay draws new masks.
+        """
+        if getattr(self, "_graphs", None) is None:
+            warm = self.step(videos, caption_tokens, caption_lengths, **others)   # eager step (fills caches)
+            self._static = [videos.clone(), caption_tokens.clone(), caption_lengths.clone(),
+                            {k: (v.clone() if torch.is_tensor(v) else v) for k, v in others.items()}]
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            gen = self.model.generator
+            if gen is not None and hasattr(g1, "register_generator_state"):
+                g1.register_generator_state(gen)
+            with torch.cuda.graph(g1):
+                self._static_out = self._forward_backward(*self._static)
+            self._set_hyper()
+            self.iteration -= 1                                               # capture does not count as a step
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._static_clip = self._optimizer_kernels()
+            self._graphs = (g1, g2)
+            return warm                        # capturing records kernels, it does not run them
+        sv, st, sl, so = self._static
+        sv.copy_(videos)
+        st.copy_(caption_tokens)
+        sl.copy_(caption_lengths)
+        for k, v in others.items():
+            if torch.is_tensor(v):
+                so[k].copy_(v)
+        self._graphs[0].replay()
+        self.all_reduce_grads()
+        lr = self._set_hyper()
+        self._graphs[1].replay()
+        self.model.mark_updated()
+        sq_slot, sc_slot, sq_img, sc_img = self._static_out
+        loss_slot, loss_img = float(sq_slot.item()) * sc_slot, float(sq_img.item()) * sc_img
+        return {"loss": loss_slot + loss_img, "pred_slot_mse": loss_slot, "pred_img_mse": loss_img,
+                "grad_norm": float(self._static_clip[1].item()), "lr": lr}
