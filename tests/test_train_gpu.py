@@ -28,10 +28,11 @@ def _ag():
     return autograd
 
 
-@pytest.mark.parametrize("rows", [100, 512])
+@pytest.mark.parametrize("rows", [100, 512, 4096])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
 def test_linear_backward(act, rows):
-    """ rows = 100: generic fp32 batched GEMM; rows = 512 (M = 1536): the bf16x6 split GEMM on transposed copies """
+    """ rows = 100: generic fp32 batched GEMM; rows = 512 (M = 1536): the bf16x6 split GEMM on transposed
+    copies; rows = 4096 (M = 12288): split-K weight gradient (batched partial products + column sum) """
     ag = _ag()
     from textocvp_amd import kernels as K
     N, Kd = 192, 128

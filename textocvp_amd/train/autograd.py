@@ -138,7 +138,20 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
         # it wants transposed are copied (data movement).  Everything else takes the generic fp32 kernel.
         fast = M >= 1024 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
         if W.requires_grad:                               # dW (N, K) = g^T (N, M) x (M, K)
-            if fast:
+            splits = min(16, M // 512)
+            if fast and M >= 8192 and (N // 64) * (Kd // 64) < 128 and M % splits == 0:
+                # small weight, long reduction: a single GEMM has too few output tiles to fill the chip.
+                # Split-K: one batched launch writes `splits` partial products, a column sum adds them.
+                Mc = M // splits
+                part = torch.empty((splits, N * Kd), device=g.device, dtype=torch.float32)
+                bmm(g, x2, part, N, Kd, Mc, N, Kd, Kd, transA=True, batch=(splits, 1),
+                    sA=(Mc * N, 0), sB=(Mc * Kd, 0), sC=(N * Kd, 0))
+                dW = colsum(part).reshape(N, Kd)
+                if W.grad is None:
+                    W.grad = dW
+                else:
+                    axpby(dW, W.grad, 1.0, 1.0)
+            elif fast:
                 gT, xT = g.t().contiguous(), x2.t().contiguous()
                 if W.grad is None:
                     W.grad = K.linear(gT, xT, precision="bf16x6")
