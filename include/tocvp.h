@@ -126,6 +126,11 @@ int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows, c
 int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                   float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                   const int32_t* key_len, void* stream);
+/* same as tocvp_mha_f32 with the score product Q K^T on the f16 matrix cores (f16x3 split operands,
+ * fp32-class, |q|, |k| < 255); softmax and P V stay exact fp32 */
+int tocvp_mha_qk16_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                       float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
+                       const int32_t* key_len, void* stream);
 /* same, O written as operand planes: (B*Tq, nsplit, H*dh) bf16 (nsplit 2 or 3) or, nsplit 22,
  * (B*Tq, 2, H*dh) fp16 planes of 2^8 O */
 int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

@@ -30,9 +30,34 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
-template <int DH>
+// QK16: the score product S^T = K Q^T runs on the f16 matrix cores with split operands (hi + lo fp16
+// planes of 2^8 q / 2^8 k, three v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of
+// gemm_bf16.hip Elem<true>, |q|, |k| < 255): 12 matrix instructions of 32 cycles per 32x32 score tile at
+// dh = 64 instead of 32 of 64 cycles.  The Q / K images keep their footprint (two 2-byte planes = one fp32)
+// and their row stride, the accumulator layout is the same, so softmax and P V (exact fp32 MFMA) are shared.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_qk(float* row, int c, f32x4 v, int DH, bool qk16) {
+    if (!qk16) {
+        *reinterpret_cast<f32x4*>(row + c) = v;
+        return;
+    }
+    h16x4 hi, lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float X = __builtin_amdgcn_fmed3f(v[u] * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
+        hi[u] = (_Float16)X;
+        lo[u] = (_Float16)(X - (float)hi[u]);
+    }
+    unsigned char* b = reinterpret_cast<unsigned char*>(row);
+    *reinterpret_cast<h16x4*>(b + c * 2) = hi;                 // [DH hi | DH lo | 16 B pad] per row
+    *reinterpret_cast<h16x4*>(b + DH * 2 + c * 2) = lo;
+}
+
+template <int DH, bool QK16>
 __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
-    constexpr int QS = DH + 4;          // padded row stride of Q / K tiles
+    constexpr int QS = DH + 4;          // padded row stride of Q / K tiles (floats; = 2 fp16 planes + pad)
     constexpr int F4 = DH / 4;          // float4 per row
     constexpr int ND = DH / 32;         // 32-wide blocks of the head dim
     __shared__ __attribute__((aligned(16))) float lds[128 * QS + 32 * QS + 32 * DH];
@@ -61,7 +86,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         const int r = i / F4, c = (i % F4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (q0 + r < p.Tq) v = *reinterpret_cast<const f32x4*>(Qb + (size_t)(q0 + r) * p.ldq + c);
-        *reinterpret_cast<f32x4*>(Qs + r * QS + c) = v;
+        store_qk(Qs + r * QS, c, v, DH, QK16);
     }
 
     const bool active = (q0 + wave * 32) < p.Tq;   // wave-uniform
@@ -83,7 +108,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
                 kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
                 vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
             }
-            *reinterpret_cast<f32x4*>(Ks + r * QS + c) = kv;
+            store_qk(Ks + r * QS, c, kv, DH, QK16);
             *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
         }
         __syncthreads();
@@ -93,14 +118,29 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float* ka = Ks + l31 * QS + 4 * h;
-        const float* qa = Qs + (wave * 32 + l31) * QS + 4 * h;
+        if (QK16) {
+            const unsigned char* ka = reinterpret_cast<const unsigned char*>(Ks + l31 * QS) + h * 16;
+            const unsigned char* qa = reinterpret_cast<const unsigned char*>(Qs + (wave * 32 + l31) * QS) + h * 16;
 #pragma unroll
-        for (int j = 0; j < DH / 8; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ka + 8 * j);
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(qa + 8 * j);
+            for (int ks = 0; ks < DH / 16; ++ks) {
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(ka + ks * 32);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(ka + ks * 32 + DH * 2);
+                const h16x8 bh = *reinterpret_cast<const h16x8*>(qa + ks * 32);
+                const h16x8 bl = *reinterpret_cast<const h16x8*>(qa + ks * 32 + DH * 2);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, s, 0, 0, 0);
+            }
+        } else {
+            const float* ka = Ks + l31 * QS + 4 * h;
+            const float* qa = Qs + (wave * 32 + l31) * QS + 4 * h;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s = mfma32(a[u], bq[u], s);
+            for (int j = 0; j < DH / 8; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ka + 8 * j);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(qa + 8 * j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s = mfma32(a[u], bq[u], s);
+            }
         }
 
         // online softmax over keys: in-lane over 16 regs + the other lane half
@@ -108,7 +148,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb * 32 + acc_row(r, h);
-            float sv = s[r] * p.scale;
+            float sv = s[r] * (QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale);
             if (p.bias && key < kv_len) {
                 const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
                 sv += p.bias[((size_t)head * p.Tq + q) * p.Tk + key];
@@ -173,7 +213,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
 static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       float* O, int ldo, void* Osplit, int nsplit, int B, int H, int Tq, int Tk,
                       int dh, float scale, const int32_t* key_len, void* stream,
-                      const float* bias = nullptr) {
+                      const float* bias = nullptr, bool qk16 = false) {
     TOCVP_CHECK_ARG(Q && K && V && (O || Osplit));
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq > 0 && Tk > 0);
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
@@ -188,10 +228,13 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
     MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias};
     dim3 grid((Tq + 127) / 128, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dh == 64)
-        hipLaunchKernelGGL(mha_f32_kernel<64>, grid, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(mha_f32_kernel<32>, grid, dim3(256), 0, s, p);
+    if (dh == 64) {
+        if (qk16) hipLaunchKernelGGL((mha_f32_kernel<64, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mha_f32_kernel<64, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (qk16) hipLaunchKernelGGL((mha_f32_kernel<32, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mha_f32_kernel<32, false>), grid, dim3(256), 0, s, p);
+    }
     return tocvp_launch_status();
 }
 
@@ -200,6 +243,13 @@ extern "C" int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, c
                              float scale, const int32_t* key_len, void* stream) {
     return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, Tq, Tk, dh, scale, key_len,
                       stream);
+}
+
+extern "C" int tocvp_mha_qk16_f32(const float* Q, int ldq, const float* K, int ldk, const float* V,
+                                  int ldv, float* O, int ldo, int B, int H, int Tq, int Tk, int dh,
+                                  float scale, const int32_t* key_len, void* stream) {
+    return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, Tq, Tk, dh, scale, key_len,
+                      stream, nullptr, true);
 }
 
 extern "C" int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V,

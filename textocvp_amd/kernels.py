@@ -62,6 +62,10 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_mha_qk16_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_slot_attn_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_slot_attn_iter_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -464,6 +468,11 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
     return y.reshape(x.shape)
 
 
+# score product of the attention kernels: "f16x3" (split fp16 operands on the f16 matrix cores, fp32-class,
+# |q|, |k| < 255) or "fp32" (exact fp32 MFMA); softmax and P V are exact fp32 either way
+_ATTN_QK16 = os.environ.get("TOCVP_ATTN_QK", "f16x3") != "fp32"
+
+
 def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     """
     q: (B, Tq, E) view with unit last stride (may be a column slice of a fused projection);
@@ -492,9 +501,9 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
                "tocvp_mha_split_bf16")
         return SplitAct(o, (B, Tq, E))
     o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
-    _check(lib().tocvp_mha_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1),
-                               _ptr(o), E, B, heads, Tq, Tk, dh, float(scale), _ptr(key_len),
-                               _stream()), "tocvp_mha_f32")
+    fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
+    _check(fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
+              dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32")
     return o
 
 
