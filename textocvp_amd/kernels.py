@@ -501,6 +501,8 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
                "tocvp_mha_split_bf16")
         return SplitAct(o, (B, Tq, E))
     o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
+    if _ATTN_QK16 and _CHECK_RANGE:
+        _check_f16_range(max(float(q.abs().max()), float(k.abs().max())), "attention q / k (f16x3 scores)")
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
     _check(fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
               dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32")

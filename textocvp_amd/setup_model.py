@@ -151,7 +151,7 @@ def calibrate_precision(decomp_model, predictor, videos, num_context, num_preds,
     while |activation| < 255 and |weight| < 63 (operands saturate beyond); this runs the path once with
     every such kernel checking its operands (kernels._CHECK_RANGE) and, where a check trips, moves the
     owning module to the range-free arithmetic (decoder convs -> bf16x3, predictor GEMMs -> bf16x6,
-    encoder / DINOSAUR decoder -> fp32 MFMA) and retries.  Returns {module: mode} of what was changed.
+    encoder / DINOSAUR decoder -> fp32 MFMA, attention scores -> fp32 MFMA) and retries.  Returns {module: mode} of what was changed.
     """
     from . import kernels as K
     from .evaluator import forward_eval
@@ -173,6 +173,10 @@ def calibrate_precision(decomp_model, predictor, videos, num_context, num_preds,
             except K.TocvpError as err:
                 if "range" not in str(err):
                     raise
+                if "attention" in str(err) and K._ATTN_QK16:
+                    K._ATTN_QK16 = False                     # process-wide: exact fp32 score products
+                    changed[("kernels", "_ATTN_QK16")] = False
+                    continue
                 for mod, attr, table in fallbacks:
                     cur = getattr(mod, attr, None) if mod is not None else None
                     if cur in table and (type(mod).__name__, attr) not in changed:
