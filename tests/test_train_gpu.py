@@ -449,3 +449,26 @@ def test_graph_replayed_steps_equal_eager_steps():
     assert res[0][0][0]["loss"] != res[0][0][2]["loss"]                       # the weights really moved
     for n in res[0][1]:
         assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 2e-6, n     # three steps of at most lr = 1e-4
+
+
+@pytest.mark.parametrize("M,N,Kd,tA,tB,ld_pad", [(70, 50, 33, False, False, 0), (64, 64, 64, True, False, 0),
+                                               (130, 36, 300, False, True, 0), (37, 128, 20, True, True, 4),
+                                               (300, 300, 64, False, True, 0), (45, 31, 18, True, False, 1)])
+def test_bmm_generic(M, N, Kd, tA, tB, ld_pad):
+    """ strided / batched fp32 GEMM: both transpose flags, ragged edges, aligned (16-byte loads) and odd leading
+    dimensions (element loads), accumulate, alpha """
+    ag = _ag()
+    nb1, nb2 = 2, 3
+    a_shape = (Kd, M + ld_pad) if tA else (M, Kd + ld_pad)
+    b_shape = (N, Kd + ld_pad) if tB else (Kd, N + ld_pad)
+    A = rnd("bA", (nb1, nb2) + a_shape)
+    B = rnd("bB", (nb1, nb2) + b_shape)
+    C0 = rnd("bC", (nb1, nb2, M, N))
+    Aop = A[..., :M].transpose(-1, -2) if tA else A[..., :Kd]
+    Bop = B[..., :Kd].transpose(-1, -2) if tB else B[..., :N]
+    ref = 0.5 * (Aop.double() @ Bop.double()) + C0.double()
+    Ad, Bd, Cd = A.to(DEV), B.to(DEV), C0.to(DEV).clone()
+    ag.bmm(Ad, Bd, Cd, M, N, Kd, a_shape[1], b_shape[1], N, transA=tA, transB=tB, batch=(nb1, nb2),
+           sA=(nb2 * a_shape[0] * a_shape[1], a_shape[0] * a_shape[1]),
+           sB=(nb2 * b_shape[0] * b_shape[1], b_shape[0] * b_shape[1]), sC=(nb2 * M * N, M * N), alpha=0.5, acc=True)
+    assert rel_err(Cd, ref) < 1e-5

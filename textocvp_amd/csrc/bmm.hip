@@ -9,8 +9,8 @@
 //
 // 64 x 64 tile per 4-wave workgroup (32 x 32 per wave), 16-deep k-tiles staged through LDS as
 // [row][k] images for BOTH operands (20-word rows: conflict-free ds_read_b128), any M / N / K (zero
-// fill on load, masked stores).  Loads are element-wise with the thread order following the
-// operand's contiguous axis; this kernel is built for generality, not for the roofline.
+// fill on load, masked stores).  Loads are 16 bytes per lane along the operand's contiguous axis when the
+// addresses allow it, element-wise otherwise; built for generality, not for the roofline.
 #include "common.h"
 
 namespace {
@@ -22,6 +22,7 @@ struct BmmArgs {
     int transA, transB, nb2;
     int M, N, K;
     float alpha; int accumulate;
+    int vec;                 // every base pointer and batch stride is a multiple of 16 bytes
 };
 
 constexpr int BT = 64, KT = 16, KS = KT + 4;
@@ -42,21 +43,75 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(BmmArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // 16-byte loads along each operand's contiguous axis when every address involved is 16-byte aligned
+    // (leading dimensions, batch strides and base pointers multiples of 4 floats); element-wise otherwise
+    const bool vecA = p.vec && (p.lda & 3) == 0, vecB = p.vec && (p.ldb & 3) == 0;
+
     for (int k0 = 0; k0 < p.K; k0 += KT) {
         __syncthreads();
+        // ---- A image: As[m][k] = op(A)[m0+m][k0+k]   (one float4 per thread = the whole 64 x 16 tile)
+        if (vecA) {
+            if (!p.transA) {
+                const int m = t >> 2, k4 = (t & 3) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m0 + m < p.M) {
+                    const float* src = A + (size_t)(m0 + m) * p.lda + k0 + k4;
+                    if (k0 + k4 + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
+                    else
+                        for (int u = 0; u < 4; ++u) if (k0 + k4 + u < p.K) v[u] = src[u];
+                }
+                *reinterpret_cast<f32x4*>(As + m * KS + k4) = v;
+            } else {
+                const int k = t >> 4, m4 = (t & 15) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k0 + k < p.K) {
+                    const float* src = A + (size_t)(k0 + k) * p.lda + m0 + m4;
+                    if (m0 + m4 + 3 < p.M) v = *reinterpret_cast<const f32x4*>(src);
+                    else
+                        for (int u = 0; u < 4; ++u) if (m0 + m4 + u < p.M) v[u] = src[u];
+                }
 #pragma unroll
-        for (int i = 0; i < (BT * KT) / 256; ++i) {
-            const int idx = t + 256 * i;
-            // A image: As[m][k] = op(A)[m0+m][k0+k]
-            {
+                for (int u = 0; u < 4; ++u) As[(m4 + u) * KS + k] = v[u];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (BT * KT) / 256; ++i) {
+                const int idx = t + 256 * i;
                 const int m = p.transA ? idx % BT : idx / KT, k = p.transA ? idx / BT : idx % KT;
                 float v = 0.f;
                 if (m0 + m < p.M && k0 + k < p.K)
                     v = p.transA ? A[(size_t)(k0 + k) * p.lda + m0 + m] : A[(size_t)(m0 + m) * p.lda + k0 + k];
                 As[m * KS + k] = v;
             }
-            // B image: Bs[n][k] = op(B)[k0+k][n0+n]
-            {
+        }
+        // ---- B image: Bs[n][k] = op(B)[k0+k][n0+n]
+        if (vecB) {
+            if (p.transB) {
+                const int n = t >> 2, k4 = (t & 3) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n0 + n < p.N) {
+                    const float* src = B + (size_t)(n0 + n) * p.ldb + k0 + k4;
+                    if (k0 + k4 + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
+                    else
+                        for (int u = 0; u < 4; ++u) if (k0 + k4 + u < p.K) v[u] = src[u];
+                }
+                *reinterpret_cast<f32x4*>(Bs + n * KS + k4) = v;
+            } else {
+                const int k = t >> 4, n4 = (t & 15) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k0 + k < p.K) {
+                    const float* src = B + (size_t)(k0 + k) * p.ldb + n0 + n4;
+                    if (n0 + n4 + 3 < p.N) v = *reinterpret_cast<const f32x4*>(src);
+                    else
+                        for (int u = 0; u < 4; ++u) if (n0 + n4 + u < p.N) v[u] = src[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Bs[(n4 + u) * KS + k] = v[u];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (BT * KT) / 256; ++i) {
+                const int idx = t + 256 * i;
                 const int n = p.transB ? idx / KT : idx % BT, k = p.transB ? idx % KT : idx / BT;
                 float v = 0.f;
                 if (n0 + n < p.N && k0 + k < p.K)
@@ -101,8 +156,9 @@ extern "C" int tocvp_bmm_f32(const float* A, int lda, long sA1, long sA2, int tr
     TOCVP_CHECK_ARG(lda > 0 && ldb > 0 && ldc > 0);
     TOCVP_CHECK_ARG((long)nb1 * nb2 <= 65535);
     if (nb1 == 0 || M == 0 || N == 0) return TOCVP_OK;
+    const int vec = tocvp_aligned16(A) && tocvp_aligned16(B) && ((sA1 | sA2 | sB1 | sB2) & 3) == 0;
     BmmArgs a{A, B, C, sA1, sA2, sB1, sB2, sC1, sC2, lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0, nb2,
-              M, N, K, alpha, accumulate ? 1 : 0};
+              M, N, K, alpha, accumulate ? 1 : 0, vec};
     const dim3 grid((N + BT - 1) / BT, (M + BT - 1) / BT, nb1 * nb2);
     hipLaunchKernelGGL(bmm_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return tocvp_launch_status();
