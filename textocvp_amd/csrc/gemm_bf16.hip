@@ -712,6 +712,12 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
         return tocvp_launch_status();
     }
     if (big_tiles < 192) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
+    static const int variant = []() {
+        const char* e = getenv("TOCVP_GEMM_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    if (variant == 1 && big_tiles >= 1024) return launch_wfrag<2, 256, 128, 64, 64, 8, 2, true>(p, s);
+    if (variant == 2) return launch_wfrag<2, 128, 128, 64, 32, 8, 2, true>(p, s);
     return launch_wfrag<2, 128, 128, 64, 64, 4, 2, true>(p, s);
 }
 
