@@ -30,11 +30,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// QK16: the score product S^T = K Q^T runs on the f16 matrix cores with split operands (hi + lo fp16
-// planes of 2^8 q / 2^8 k, three v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of
-// gemm_bf16.hip Elem<true>, |q|, |k| < 255): 12 matrix instructions of 32 cycles per 32x32 score tile at
-// dh = 64 instead of 32 of 64 cycles.  The Q / K images keep their footprint (two 2-byte planes = one fp32)
-// and their row stride, the accumulator layout is the same, so softmax and P V (exact fp32 MFMA) are shared.
+// QK16: BOTH products run on the f16 matrix cores with split operands (hi + lo fp16 planes of 2^8 x, three
+// v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of gemm_bf16.hip Elem<true>, |q|, |k|,
+// |v| < 255): per 32-key tile and 32 queries at dh = 64, 12 + 12 matrix instructions of 32 cycles instead of
+// 32 + 32 of 64 cycles.
+//  * scores S^T = K Q^T: the Q / K images hold two 2-byte planes per element (same footprint and row stride
+//    as fp32), the accumulator layout does not depend on the operand type, so the softmax code is shared;
+//  * O^T += V^T P^T: the exponentiated score tile is used as the B operand straight from its accumulator
+//    registers (registers 8s..8s+7 -> fragment of 16-key step s, split into hi / lo in registers); that
+//    fixes the key order inside a step, and the A operand (V^T, image transposed while staged) follows it.
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
@@ -60,7 +64,8 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
     constexpr int QS = DH + 4;          // padded row stride of Q / K tiles (floats; = 2 fp16 planes + pad)
     constexpr int F4 = DH / 4;          // float4 per row
     constexpr int ND = DH / 32;         // 32-wide blocks of the head dim
-    __shared__ __attribute__((aligned(16))) float lds[128 * QS + 32 * QS + 32 * DH];
+    constexpr int VTB = 144;            // QK16: bytes per row of the transposed V image [dh][32 keys hi | lo | pad]
+    __shared__ __attribute__((aligned(16))) float lds[128 * QS + 32 * QS + (QK16 ? DH * (VTB / 4) : 32 * DH)];
     float* Qs = lds;
     float* Ks = lds + 128 * QS;
     float* Vs = Ks + 32 * QS;
@@ -109,7 +114,20 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
                 vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
             }
             store_qk(Ks + r * QS, c, kv, DH, QK16);
-            *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
+            if (QK16) {
+                // transposed fp16 planes of 2^8 v: VT[d][key], so that a lane of the P V product reads
+                // runs of 4 consecutive keys of ITS head-dim row
+                unsigned char* vt = reinterpret_cast<unsigned char*>(Vs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float X = __builtin_amdgcn_fmed3f(vv[u] * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
+                    const _Float16 hi = (_Float16)X;
+                    *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + r * 2) = hi;
+                    *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + 64 + r * 2) = (_Float16)(X - (float)hi);
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
+            }
         }
         __syncthreads();
         if (!active) continue;
@@ -174,17 +192,45 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
             for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
 
         // O^T (dh x 32 queries) += V^T (dh x keys) * P^T (keys x queries); P^T is `s` as it stands
+        if (QK16) {
+            // f16x3: registers 8ks .. 8ks+7 of the score tile ARE the B fragment of 16-key step ks, with
+            // element j of lane half h = key 16ks + 8(j >> 2) + 4h + (j & 3); the A fragment (V^T) takes
+            // the same keys: two runs of 4 consecutive keys of head-dim row l31.
+            const unsigned char* vt = reinterpret_cast<const unsigned char*>(Vs);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* va = Vs + acc_row(r, h) * DH + l31;
+            for (int ks = 0; ks < 2; ++ks) {
+                h16x8 ph, pl;
 #pragma unroll
-            for (int d = 0; d < ND; ++d) oacc[d] = mfma32(va[32 * d], s[r], oacc[d]);
+                for (int j = 0; j < 8; ++j) {
+                    const float P = s[8 * ks + j] * TOCVP_F16X3_ACT_SCALE;      // in [0, 256]
+                    ph[j] = (_Float16)P;
+                    pl[j] = (_Float16)(P - (float)ph[j]);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const unsigned char* va = vt + (d * 32 + l31) * VTB + (16 * ks + 4 * h) * 2;
+                    const h16x4 h0 = *reinterpret_cast<const h16x4*>(va), h1 = *reinterpret_cast<const h16x4*>(va + 16);
+                    const h16x4 l0 = *reinterpret_cast<const h16x4*>(va + 64), l1 = *reinterpret_cast<const h16x4*>(va + 80);
+                    const h16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const h16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc[d], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* va = Vs + acc_row(r, h) * DH + l31;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) oacc[d] = mfma32(va[32 * d], s[r], oacc[d]);
+            }
         }
     }
 
     // ---- epilogue: normalise, transpose through this wave's own Q rows in LDS, coalesced store
     if (active) {
-        const float inv = 1.0f / l_run;
+        const float inv = (QK16 ? 1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE) : 1.f) / l_run;
         float* os = Qs + (wave * 32) * QS;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
