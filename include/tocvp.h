@@ -126,8 +126,8 @@ int tocvp_layernorm_split_bf16(const float* x, const float* add, int add_rows, c
 int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                   float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                   const int32_t* key_len, void* stream);
-/* same as tocvp_mha_f32 with the score product Q K^T on the f16 matrix cores (f16x3 split operands,
- * fp32-class, |q|, |k| < 255); softmax and P V stay exact fp32 */
+/* same as tocvp_mha_f32 with both products (Q K^T and P V) on the f16 matrix cores (f16x3 split operands,
+ * fp32-class, |q|, |k|, |v| < 255); the softmax stays fp32 */
 int tocvp_mha_qk16_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                        float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                        const int32_t* key_len, void* stream);

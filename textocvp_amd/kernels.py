@@ -468,8 +468,8 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
     return y.reshape(x.shape)
 
 
-# score product of the attention kernels: "f16x3" (split fp16 operands on the f16 matrix cores, fp32-class,
-# |q|, |k| < 255) or "fp32" (exact fp32 MFMA); softmax and P V are exact fp32 either way
+# matrix products of the attention kernel (Q K^T and P V): "f16x3" (split fp16 operands on the f16 matrix
+# cores, fp32-class, |q|, |k|, |v| < 255) or "fp32" (exact fp32 MFMA); the softmax is fp32 either way
 _ATTN_QK16 = os.environ.get("TOCVP_ATTN_QK", "f16x3") != "fp32"
 
 
@@ -502,7 +502,8 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
         return SplitAct(o, (B, Tq, E))
     o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
     if _ATTN_QK16 and _CHECK_RANGE:
-        _check_f16_range(max(float(q.abs().max()), float(k.abs().max())), "attention q / k (f16x3 scores)")
+        _check_f16_range(max(float(q.abs().max()), float(k.abs().max()), float(v.abs().max())),
+                         "attention q / k / v (f16x3 products)")
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
     _check(fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
               dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32")
