@@ -103,15 +103,34 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
     const int nkb = (kv_len + 31) / 32;
+    // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
+    // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
+    constexpr int NITM = (32 * F4 + 255) / 256;                    // items per thread: DH 64 -> 2, DH 32 -> 1
+    f32x4 kreg[NITM], vreg[NITM];
+    auto kv_load = [&](int kb) {
+#pragma unroll
+        for (int it = 0; it < NITM; ++it) {
+            const int i = min(t + 256 * it, 32 * F4 - 1);
+            const int r = i / F4, c = (i % F4) * 4;
+            const int key = min(kb * 32 + r, p.Tk - 1);
+            kreg[it] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
+            vreg[it] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
+        }
+    };
+    kv_load(0);
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();   // previous tile fully consumed (also orders the Q staging)
-        for (int i = t; i < 32 * F4; i += 256) {
+#pragma unroll
+        for (int it = 0; it < NITM; ++it) {
+            const int i = t + 256 * it;
+            if (i >= 32 * F4) continue;
             const int r = i / F4, c = (i % F4) * 4;
-            const int key = kb * 32 + r;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < p.Tk) {
-                kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
-                vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
+            const bool valid = kb * 32 + r < p.Tk;
+            f32x4 kv = kreg[it], vv = vreg[it];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kv[u] = valid ? kv[u] : 0.f;
+                vv[u] = valid ? vv[u] : 0.f;
             }
             store_qk(Ks + r * QS, c, kv, DH, QK16);
             if (QK16) {
@@ -129,6 +148,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
                 *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
             }
         }
+        kv_load(min(kb + 1, nkb - 1));
         __syncthreads();
         if (!active) continue;
 
