@@ -6,9 +6,10 @@ seeded inputs / weights.  Needs a real MI355X (pytest -m gpu).
 Tolerance = the north-star bar: 1e-4 absolute on slots, masks and rendered pixels, identical
 argmax_K(masks) maps (slot-index permutation).  Unit fixtures use 5e-5 where the arithmetic is
 fp32-class.  The suite runs in the default arithmetic (decoder convs f16f8, predictor GEMMs
-f16x3, everything else exact fp32 MFMA) and, with TOCVP_DECODER_PRECISION=fp32
-TOCVP_PREDICTOR_PRECISION=fp32, in the all-fp32 mode.
+f16x3, the rest per DESIGN.md section 3) and, with TOCVP_PRECISION=fp32, in the all-fp32 mode.
 """
+
+import os
 
 import numpy as np
 import pytest
@@ -171,6 +172,7 @@ def test_fp16_plane_range_check(k7, monkeypatch):
         K.conv5x5_f16f8(x, K.split_conv_weights_f16f8(w), torch.zeros(64, device=DEV))
 
 
+@pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32", reason="all-fp32 mode has no fp16-plane modules")
 @torch.no_grad()
 def test_calibrate_precision_moves_out_of_range_modules():
     """ a checkpoint whose decoder activations leave the fp16-plane range is moved to the range-free

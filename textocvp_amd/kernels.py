@@ -13,6 +13,7 @@ import weakref
 import torch
 
 from . import build as _build
+from .precision import knob as _knob
 
 _c_float_p = ctypes.c_void_p
 _LIB = None
@@ -470,7 +471,7 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
 
 # matrix products of the attention kernel (Q K^T and P V): "f16x3" (split fp16 operands on the f16 matrix
 # cores, fp32-class, |q|, |k|, |v| < 255) or "fp32" (exact fp32 MFMA); the softmax is fp32 either way
-_ATTN_QK16 = os.environ.get("TOCVP_ATTN_QK", "f16x3") != "fp32"
+_ATTN_QK16 = _knob("TOCVP_ATTN_QK", "f16x3") != "fp32"
 
 
 def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):

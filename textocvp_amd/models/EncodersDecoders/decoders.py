@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import kernels as K
+from ...precision import knob
 from ..Blocks.model_blocks import ConvBlock
 from ..Blocks.model_utils import Derived
 
@@ -65,7 +66,7 @@ class ConvDecoder(nn.Module):
         # the bf16 matrix cores, ~2^-16 per-product error, 5.3x fewer matrix cycles) or "f16f8"
         # (f16 main product + two e4m3 cross products: 2/3 of the bf16x3 cycles, ~2.3x its error;
         # needs W % 64 == 0, other shapes take the bf16x3 kernel)
-        self.conv_precision = os.environ.get("TOCVP_DECODER_PRECISION", "f16f8")
+        self.conv_precision = knob("TOCVP_DECODER_PRECISION", "f16f8")
         self.pass_major = os.environ.get("TOCVP_CONV_PASS_MAJOR", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
@@ -209,8 +210,8 @@ class MLPPatchDecoder(nn.Module):
                 in_dim=out_dim - 1, hidden_dim=hidden_dim, num_layers=self.num_layers_cnn,
                 patch_size=self.patch_size)
         self._derived = Derived()
-        self.mlp_precision = os.environ.get("TOCVP_DECODER_MLP_PRECISION", "f16x3")
-        self.conv_precision = os.environ.get("TOCVP_DECODER_CNN_PRECISION", "f16x3")   # image head convs
+        self.mlp_precision = knob("TOCVP_DECODER_MLP_PRECISION", "f16x3")
+        self.conv_precision = knob("TOCVP_DECODER_CNN_PRECISION", "f16x3")   # image head convs
 
     def _build_conv_patch_decoder(self, in_dim, hidden_dim, num_layers, patch_size):
         """ same layer / channel / upsampling schedule as the reference (decoders.py:325-365) """

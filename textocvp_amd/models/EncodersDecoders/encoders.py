@@ -8,6 +8,7 @@ import os
 import torch.nn as nn
 
 from ... import kernels as K
+from ...precision import knob
 from ..Blocks.model_blocks import ConvBlock
 from ..Blocks.model_utils import Derived
 
@@ -46,7 +47,7 @@ class SimpleConvEncoder(nn.Module):
         self.encoder = nn.Sequential(*blocks)
         self._derived = Derived()
         # convs 1..: "f16x3" (split fp16 operands on the f16 matrix cores, fp32-class) or "fp32" (exact MFMA)
-        self.conv_precision = os.environ.get("TOCVP_ENCODER_PRECISION", "f16x3")
+        self.conv_precision = knob("TOCVP_ENCODER_PRECISION", "f16x3")
 
     def forward_nhwc(self, x):
         """ x: (n, 3, H, W) view of contiguous image planes -> (n, H, W, C) """

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import kernels as K
+from ...precision import knob
 from ..Blocks.attention import AdaptedEncoderBlock
 from ..Blocks.model_blocks import TemporalPositionalEncoding
 from ..Blocks.model_utils import require_inference
@@ -54,7 +55,7 @@ class BaseTextOCVP(nn.Module):
         self._text_cache = None
         # arithmetic of the predictor GEMMs: "fp32" | "bf16x3" | "bf16x6" | "f16x3" (kernels.gemm_precision)
         # f16x3 = two fp16 planes per operand, 3 matrix-core products, fp32-class for |activation| < 255
-        self.gemm_precision = os.environ.get("TOCVP_PREDICTOR_PRECISION", "f16x3")
+        self.gemm_precision = knob("TOCVP_PREDICTOR_PRECISION", "f16x3")
         self.last_layer_newest_frame_only = os.environ.get("TOCVP_LAST_LAYER_SUBSET", "1") != "0"
 
     def _instantiate_text_encoder(self):

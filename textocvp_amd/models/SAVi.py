@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
+from ..precision import knob
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
 from .Blocks.model_blocks import SoftPositionEmbed
@@ -44,7 +45,7 @@ class SAVi(nn.Module):
         self.in_channels = in_channels
         self.mlp_encoder_dim = mlp_encoder_dim
         # arithmetic of the per-pixel encoder MLP and k/v projection GEMMs (shapes that fit the split kernel)
-        self.encoder_gemm_precision = os.environ.get("TOCVP_ENCODER_GEMM_PRECISION", "f16x3")
+        self.encoder_gemm_precision = knob("TOCVP_ENCODER_GEMM_PRECISION", "f16x3")
 
         self.initializer = get_initializer(mode=initializer, slot_dim=slot_dim, num_slots=num_slots)
         self.transition_module = get_transition_module(slot_dim=slot_dim, **transition_module)
