@@ -153,3 +153,34 @@ def test_t5_predictor_layout():
     assert not any(p.requires_grad for p in pred.predictor.text_encoder.parameters())
     with torch.no_grad(), pytest.raises(KeyError):
         pred(torch.zeros(1, 3, 7, 128), caption_tokens=torch.zeros(1, 4, dtype=torch.int64))
+
+
+def test_precision_knobs(monkeypatch):
+    """ per-module arithmetic knobs and the all-fp32 master switch (host logic, no kernels) """
+    from textocvp_amd.precision import knob
+    monkeypatch.delenv("TOCVP_PRECISION", raising=False)
+    monkeypatch.delenv("TOCVP_DECODER_PRECISION", raising=False)
+    assert knob("TOCVP_DECODER_PRECISION", "f16f8") == "f16f8"
+    monkeypatch.setenv("TOCVP_PRECISION", "fp32")
+    assert knob("TOCVP_DECODER_PRECISION", "f16f8") == "fp32"
+    monkeypatch.setenv("TOCVP_DECODER_PRECISION", "bf16x3")          # a specific knob wins over the master switch
+    assert knob("TOCVP_DECODER_PRECISION", "f16f8") == "bf16x3"
+
+
+def test_training_lr_schedule_matches_reference_shape():
+    """ linear warm-up to lr over warmup_steps (lib/schedulers.py:68-107), then CosineAnnealingLR(T_max, eta_min 1e-7)
+    (lib/setup_model.py:317-322) """
+    import math
+    import types
+    from textocvp_amd.train.step import PredictorTrainStep
+    cfg = types.SimpleNamespace(lr=1e-4, warmup_steps=2000, scheduler_steps=1e6, eta_min=1e-7)
+    lr_at = lambda it: PredictorTrainStep.lr_at(cfg, it)
+    assert lr_at(1) == pytest.approx(1e-4 / 2000)
+    assert lr_at(1000) == pytest.approx(5e-5)
+    assert lr_at(2000) == pytest.approx(1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(
+        torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), T_max=1e6, eta_min=1e-7)
+    for t in (1, 500000, 1000000):
+        expect = 1e-7 + (1e-4 - 1e-7) * (1 + math.cos(math.pi * t / 1e6)) / 2
+        assert lr_at(2000 + t) == pytest.approx(expect, rel=1e-9)
+    assert sched.get_last_lr()[0] == pytest.approx(lr_at(2000))        # closed form of the torch scheduler at t = 0
