@@ -5,48 +5,55 @@ bench.py -- predicted frames / second of the TextOCVP slot-rollout hot path on M
 One "step" = one pass of the hot path over one batch of synthetic sequences:
     SAVi encode (20 frames) -> TextOCVP_CustomTF rollout (19 steps) -> decode (19 frames)
 at BASELINE.json configs[1]: 30 slots, 64x64x3, 1 seed + 19 predicted frames.  Inputs and weights
-are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank
-runs its own batches (weak scaling, no collective inside the rollout) and the per-sequence
-metrics are all-gathered ONCE at the end (RCCL).
+are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-extra]
+
+N > 1: one process per GPU.  Under torchrun (WORLD_SIZE set) this process IS one rank; otherwise
+``--gpus N`` makes this process a launcher that starts N fresh worker processes (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment) BEFORE anything touches the GPU and
+waits for them -- it replaces the reference's nn.DataParallel wrap (base/baseEvaluator.py:142-145).
+Every rank runs its own batches (weak scaling, no collective inside the rollout); the per-sequence
+PSNR / SSIM rows are all-gathered ONCE at the end (RCCL).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline": dominant kernel (5x5 conv 64->64 on fp32 MFMA) measured live with HIP events,
-  "cpu_baseline": the CPU oracle (oracle/, kind "port") on one sequence of the same workload.
+  "roofline":     dominant kernel (decoder 5x5 conv) timed IN the timed region with HIP events,
+  "rooflines":    that entry + predictor GEMM, predictor attention and the slot-attention iteration
+                  (HBM-bound, GB/s), each timed with HIP events in one extra untimed pass,
+  "cpu_baseline": the CPU oracle (oracle/, kind "port") on a bounded sample: warm-up + 5 timed reps,
+  "extra":        the same measurement at the authors' evaluation batch (32 sequences per GPU).
 """
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NUM_SLOTS, NUM_CONTEXT, NUM_PREDS, RES = 30, 1, 19, 64
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, chip-level parameters
-BF16_MFMA_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA (same table)
+F16_MFMA_PEAK_TFLOPS = 2500.0            # dense f16 / bf16 MFMA (same table)
+HBM_PEAK_GBPS = 8000.0                   # HBM3E spec (6.3 TB/s achievable, same guide)
 CONV_GFLOP_PER_SLOT_IMAGE = 2 * RES * RES * 64 * 64 * 25 / 1e9   # 0.839: one 64->64 5x5 layer
 PATH_GFLOP_PER_FRAME = 149.5             # SURVEY.md 8(d): reference algorithm, K=30
 
-
-ARITH = {
-    ("fp32", "fp32"): "fp32",
-    ("f16f8", "f16x3"): "split operands on the matrix cores, fp32 accumulate / storage: decoder convs f16f8 "
-                        "(f16 hi product + two e4m3 cross products), predictor GEMMs and encoder convs / "
-                        "per-pixel GEMMs f16x3 (hi/lo fp16 planes, 3 products); slot attention, attention "
-                        "scores, softmax, LayerNorm exact fp32",
-    ("bf16x3", "f16x3"): "split operands on the 16-bit matrix cores (decoder convs bf16x3 = hi/lo bf16 "
-                         "planes, predictor GEMMs f16x3 = hi/lo fp16 planes; 3 products each), fp32 "
-                         "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
-    ("bf16x3", "bf16x6"): "bf16 split operands (decoder convs bf16x3, predictor GEMMs bf16x6), fp32 "
-                          "accumulate / storage; encoder, slot attention, softmax, LayerNorm fp32",
+# matrix-pipe time per algorithmic product in units of one 16-bit MFMA product, and the peak it is priced on
+CONV_MODES = {
+    "f16x3": ("conv5x5_dec_f16x3_kernel (decoder 5x5 conv 64->64, split-fp16 operands: 3 f16 MFMA products "
+              "per algorithmic product, fp32-class)", 3, F16_MFMA_PEAK_TFLOPS),
+    "bf16x3": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 operands, 3 bf16 MFMA products per "
+               "algorithmic product)", 3, F16_MFMA_PEAK_TFLOPS),
+    "f16f8": ("conv5x5_f16f8_kernel (decoder 5x5 conv 64->64, hybrid split: f16 main product + two e4m3 cross "
+              "products on the 32x32x64 scaled MFMA)", 2, F16_MFMA_PEAK_TFLOPS),
+    "fp32": ("conv5x5_mfma_kernel<64,64> (decoder 5x5 conv, exact fp32 MFMA)", 1, FP32_MFMA_PEAK_TFLOPS),
 }
+GEMM_UNITS = {22: ("f16x3", 3), 2: ("bf16x3", 3), 3: ("bf16x6", 6)}
 
 
 def parse():
@@ -57,9 +64,54 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TOCVP_BENCH_BATCH", 128)),
                     help="sequences per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batch-32 line and the per-kernel pass")
     return ap.parse_args()
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N without torchrun
+# ------------------------------------------------------------------------------------------------
+def worker_env(rank, world, port, base=None):
+    """ environment of worker ``rank`` (what torchrun would set); pure function, covered by a CPU test """
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "TOCVP_BENCH_WORKER": "1"})
+    return env
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(n, argv=None, device_count=None, popen=subprocess.Popen):
+    """
+    Start ``n`` fresh worker processes of this script and wait for them.  The launcher itself never
+    initialises the GPU (``torch.cuda.device_count()`` does not), and never exec()s.  Returns the exit code.
+    """
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count()
+    # TOCVP_DIST_BACKEND=gloo is the single-GPU rehearsal of the multi-process path: ranks share devices
+    if device_count < n and os.environ.get("TOCVP_DIST_BACKEND", "nccl") != "gloo":
+        log(f"--gpus {n} but only {device_count} GPU(s) are visible")
+        return 2
+    argv = list(sys.argv[1:] if argv is None else argv)
+    port = free_port()
+    procs = [popen([sys.executable, os.path.abspath(__file__)] + argv, env=worker_env(r, n, port))
+             for r in range(n)]
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+# ------------------------------------------------------------------------------------------------
 def host_cores():
     """ cores this process may really use: min(affinity mask, cgroup v2/v1 CPU quota) """
     cores = os.cpu_count() or 1
@@ -82,45 +134,68 @@ def host_cores():
     return cores
 
 
-def log(msg):
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
 def cpu_baseline(savi, pred):
-    """ CPU oracle (port of the reference path) on ONE sequence of the same workload. """
+    """
+    CPU oracle (port of the reference path, oracle/) on a bounded sample of the same workload:
+    1 untimed warm-up sequence, then 5 timed repetitions of a 2-sequence batch (the
+    survey saw a 79 s outlier on a noisy host, hence median AND min).
+    """
+    import torch
     from oracle import slot_rollout_oracle as O
     from textocvp_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
     ssd = {k: v.detach().cpu() for k, v in savi.state_dict().items()}
     psd = {k: v.detach().cpu() for k, v in pred.state_dict().items()}
-    nseq = int(os.environ.get("TOCVP_CPU_BASELINE_SEQS", 6))
+    nseq = int(os.environ.get("TOCVP_CPU_BASELINE_SEQS", 2))
+    reps = int(os.environ.get("TOCVP_CPU_BASELINE_REPS", 5))
     videos = synth.synth_videos(nseq, NUM_CONTEXT + NUM_PREDS, seed=0)
     tokens, lengths = synth.synth_captions(nseq, max_len=12, seed=0)
     noise = synth.synth_noise(nseq, NUM_SLOTS, 128, seed=1)
-    with torch.no_grad():   # untimed warm-up on one sequence (thread pool, MKLDNN primitives)
-        O.forward_eval(ssd, psd, videos[:1], tokens[:1], lengths[:1], noise[:1], NUM_CONTEXT,
-                       NUM_PREDS)
-        t0 = time.perf_counter()
-        O.forward_eval(ssd, psd, videos, tokens, lengths, noise, NUM_CONTEXT, NUM_PREDS)
-        dt = time.perf_counter() - t0
-    return {"value": round(nseq * NUM_PREDS / dt, 3), "unit": "predicted frames/s", "cores": cores,
-            "kind": "port",
-            "sample": f"one batch of {nseq} sequences (30 slots, 1 seed + 19 preds, 64x64) after a "
-                      f"1-sequence warm-up: {dt:.1f} s wall, torch-CPU fp32 oracle, {cores} threads"}
+    times = []
+    with torch.no_grad():
+        O.forward_eval(ssd, psd, videos[:1], tokens[:1], lengths[:1], noise[:1], NUM_CONTEXT, NUM_PREDS)
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.forward_eval(ssd, psd, videos, tokens, lengths, noise, NUM_CONTEXT, NUM_PREDS)
+            times.append(time.perf_counter() - t0)
+    med, best = statistics.median(times), min(times)
+    return {"value": round(nseq * NUM_PREDS / med, 3), "unit": "predicted frames/s", "cores": cores,
+            "kind": "port", "value_best": round(nseq * NUM_PREDS / best, 3),
+            "rep_seconds": [round(t, 2) for t in times],
+            "sample": f"{reps} timed repetitions of one batch of {nseq} sequences (30 slots, 1 seed + 19 preds, "
+                      f"64x64) after a 1-sequence warm-up; value = median ({med:.1f} s), value_best = min "
+                      f"({best:.1f} s); torch-CPU fp32 oracle, {cores} threads"}
+
+
+def arithmetic_string(savi, pred, kernels):
+    attn = "f16x3 (split fp16 operands)" if kernels._ATTN_QK16 else "exact fp32 MFMA"
+    return (f"fp32 storage / accumulation, operands split into 16-bit planes on the matrix cores: decoder convs "
+            f"{savi.decoder.conv_precision}, predictor GEMMs {pred.predictor.gemm_precision}, encoder convs "
+            f"{savi.encoder.conv_precision}, encoder / kv GEMMs {savi.encoder_gemm_precision}, attention "
+            f"QK^T and PV {attn}; slot-attention iteration, softmax, LayerNorm, GRU exact fp32")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args.gpus))          # launcher: no GPU call before or after this line
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one process per GPU; TOCVP_DIST_BACKEND=gloo lets several ranks share ONE GPU to rehearse the
-    # torchrun path on a single-GPU box (the collective then runs on host copies of the metrics)
+    # multi-process path on a single-GPU box (the collective then runs on host copies of the metrics)
     backend = os.environ.get("TOCVP_DIST_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"WORLD_SIZE={world} ranks but only {ndev} GPU(s) visible")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -128,7 +203,7 @@ def main():
         dist.init_process_group(backend=backend)     # "nccl" is RCCL on ROCm
 
     from textocvp_amd import kernels, synth
-    from textocvp_amd.evaluator import forward_eval, gather_metrics, psnr_per_frame
+    from textocvp_amd.evaluator import forward_eval, gather_metrics
     from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
 
     exp = default_exp_params(num_slots=NUM_SLOTS, num_context=NUM_CONTEXT, num_preds=NUM_PREDS)
@@ -138,130 +213,167 @@ def main():
     synth.fill_module_(pred, prefix="pred.")
     savi, pred = savi.to(dev), pred.to(dev)
 
-    B = args.batch
-    videos = synth.synth_videos(B, NUM_CONTEXT + NUM_PREDS, seed=100 + rank).to(dev)
-    tokens, lengths = synth.synth_captions(B, max_len=12, seed=100 + rank)
-    tokens, lengths = tokens.to(dev), lengths.to(dev)
-    noise = synth.synth_noise(B, NUM_SLOTS, 128, seed=200 + rank).to(dev)
+    def make_inputs(B):
+        videos = synth.synth_videos(B, NUM_CONTEXT + NUM_PREDS, seed=100 + rank).to(dev)
+        tokens, lengths = synth.synth_captions(B, max_len=12, seed=100 + rank)
+        return videos, tokens.to(dev), lengths.to(dev), synth.synth_noise(B, NUM_SLOTS, 128, seed=200 + rank).to(dev)
 
-    def step():
+    def step(inp, **kw):
+        """ the hot path + the metric step after it: fused clamp + PSNR + SSIM kernel (tocvp_psnr_ssim_f32) """
+        videos, tokens, lengths, noise = inp
         out = forward_eval(savi, pred, videos, NUM_CONTEXT, NUM_PREDS, caption_tokens=tokens,
-                           caption_lengths=lengths, init_noise=noise)
-        return psnr_per_frame(out["pred_imgs"], out["targets"])
+                           caption_lengths=lengths, init_noise=noise, **kw)
+        B, P, C, H, W = out["pred_imgs"].shape
+        psnr, ssim = kernels.psnr_ssim(out["pred_imgs"].reshape(B * P, C, H, W),
+                                       out["targets"].reshape(B * P, C, H, W), clamp01=True)
+        return torch.stack([psnr.view(B, P), ssim.view(B, P)], dim=-1)        # (B, P, 2)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(inp, warmup, steps, timer_only=("conv5x5",)):
+        for _ in range(warmup):
+            step(inp)
+        fence()
+        kernels.TIMER = kernels.LaunchTimer(only=timer_only)
+        metrics = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            metrics.append(step(inp))
+        gathered = gather_metrics(torch.cat(metrics, dim=0))      # the path's ONLY collective
+        fence()
+        elapsed = time.perf_counter() - t0
+        timer, kernels.TIMER = kernels.TIMER, None
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), timer, gathered
+
+    B = args.batch
+    inp = make_inputs(B)
     if rank == 0:
         log(f"world={world} batch/gpu={B} warmup={args.warmup} steps={args.steps}")
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if rank == 0:
-        log("warmup done, timing")
-    kernels.TIMER = kernels.LaunchTimer()
-    metrics = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        metrics.append(step())
-    all_metrics = gather_metrics(torch.cat(metrics, dim=0))     # the path's ONLY collective
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer, kernels.TIMER = kernels.TIMER, None
+    elapsed, timer, all_metrics = timed(inp, args.warmup, args.steps)
 
-    # Outside the timed region: one more pass with the decoder NOT overlapped with the rollout.
-    # In the timed steps the conv launches share the GPU with the predictor's kernels (second
-    # stream), so their in-situ duration is not a statement about the kernel alone.
-    timer_excl = None
-    if rank == 0:
-        kernels.TIMER = kernels.LaunchTimer()
-        forward_eval(savi, pred, videos, NUM_CONTEXT, NUM_PREDS, overlap_decode=False,
-                     caption_tokens=tokens, caption_lengths=lengths, init_noise=noise)
+    # Outside the timed region (rank 0): one pass with the decoder NOT overlapped with the rollout and EVERY
+    # instrumented kernel bracketed by HIP events (thousands of event pairs would perturb the timed region).
+    timer_all = None
+    if rank == 0 and not args.no_extra:
+        kernels.TIMER = kernels.LaunchTimer(only=("conv5x5", "gemm_", "mha_", "slot_attn_"))
+        step(inp, overlap_decode=False)
         torch.cuda.synchronize()
-        timer_excl, kernels.TIMER = kernels.TIMER, None
+        timer_all, kernels.TIMER = kernels.TIMER, None
 
-    t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    extra = None
+    if not args.no_extra and B != 32:
+        el32, _, _ = timed(make_inputs(32), 1, max(2, args.steps))
+        extra = {"batch_32": {"value": round(world * 32 * NUM_PREDS * max(2, args.steps) / el32, 2),
+                              "unit": "predicted frames/s", "batch_per_gpu": 32,
+                              "ms_per_step": round(1e3 * el32 / max(2, args.steps), 2),
+                              "note": "the authors' evaluation batch (scripts/05_evaluate_TextOCVP_CATER.sh); "
+                                      "decoder overlapped with the rollout on a second stream"}}
 
     if rank == 0:
         frames = world * B * NUM_PREDS * args.steps
-        conv = timer.summary().get("conv5x5_64_64")
+        cp = savi.decoder.conv_precision
+        kernel_name, units, peak = CONV_MODES.get(cp, CONV_MODES["fp32"])
+        rooflines = []
         roofline = None
+        conv = timer.summary().get("conv5x5_64_64")
         if conv and conv["launches"]:
             avg_ms = conv["total_ms"] / conv["launches"]
             gflop_per_launch = CONV_GFLOP_PER_SLOT_IMAGE * conv["units"] / conv["launches"]
             achieved = gflop_per_launch / avg_ms            # GFLOP/ms == TFLOP/s
-            traffic = None
+            traffic, traffic_from = None, None
             pmc = os.path.join(ROOT, "profiles", "conv_pmc_summary.json")
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     rec = json.load(f)
                 # only a summary taken on the kernel that is running now counts
-                if rec.get("slot_images_per_launch") and \
-                        savi.decoder.conv_precision in rec.get("kernel", ""):
+                if rec.get("slot_images_per_launch") and cp in rec.get("kernel", ""):
                     traffic = rec["hbm_bytes_per_launch"] * (
                         conv["units"] / conv["launches"]) / rec["slot_images_per_launch"]
-            # `achieved` is ALGORITHMIC flops / time; `peak` the dense MFMA peak of the 16-bit operand
-            # type the main products run on.  `matrix_units_per_product`: matrix-pipe time per
-            # algorithmic product in units of one 16-bit MFMA product (bf16x3: three bf16 products;
-            # f16f8: one f16 product + two e4m3 products at twice the f16 rate)
-            cp = savi.decoder.conv_precision
-            kernel_name, units, peak = {
-                "bf16x3": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 operands, 3 bf16 "
-                           "MFMA products per algorithmic product)", 3, BF16_MFMA_PEAK_TFLOPS),
-                "f16f8": ("conv5x5_f16f8_kernel (decoder 5x5 conv 64->64, hybrid split: f16 main product "
-                          "+ two e4m3 cross products on the 32x32x64 scaled MFMA)", 2,
-                          BF16_MFMA_PEAK_TFLOPS),
-            }.get(cp, ("conv5x5_mfma_kernel<64,64> (decoder 5x5 conv, exact fp32 MFMA)", 1,
-                       FP32_MFMA_PEAK_TFLOPS))
-            roofline = {"bound": "mfma",
-                        "kernel": kernel_name,
-                        "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    traffic_from = "profiles/conv_pmc_summary.json (rocprofv3 PMC, separate FETCH_SIZE / " \
+                                   "WRITE_SIZE passes, gfx950 x2 fetch correction; not this run)"
+            roofline = {"bound": "mfma", "kernel": kernel_name,
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4),
                         "matrix_units_per_product": units,
                         "frac_executed_mfma": round(units * achieved / peak, 4),
-                        "traffic": traffic, "launches": conv["launches"],
-                        "avg_launch_ms": round(avg_ms, 4),
-                        "gflop_per_launch": round(gflop_per_launch, 2),
+                        "traffic": traffic, "traffic_from": traffic_from, "launches": conv["launches"],
+                        "avg_launch_ms": round(avg_ms, 4), "gflop_per_launch": round(gflop_per_launch, 2),
                         "share_of_step_time": round(conv["total_ms"] / 1e3 / elapsed, 3),
-                        "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the timed region); "
-                                "below 96 sequences per GPU the decoder runs on a second stream "
-                                "concurrently with the rollout and shares the CUs; 'exclusive' is the "
-                                "same kernel in one extra untimed pass with the GPU to itself"}
-            ex = timer_excl.summary().get("conv5x5_64_64") if timer_excl else None
-            if ex and ex["launches"]:
-                ex_ms = ex["total_ms"] / ex["launches"]
-                ex_tf = CONV_GFLOP_PER_SLOT_IMAGE * ex["units"] / ex["launches"] / ex_ms
-                roofline["exclusive"] = {"avg_launch_ms": round(ex_ms, 4), "achieved": round(ex_tf, 2),
-                                         "frac": round(ex_tf / peak, 4),
-                                         "frac_executed_mfma": round(units * ex_tf / peak, 4),
-                                         "launches": ex["launches"]}
+                        "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the timed region, "
+                                "algorithmic 0.839 GFLOP per slot image and layer); frac prices ALGORITHMIC flops "
+                                "against the dense f16 peak, frac_executed_mfma counts the matrix products the "
+                                "split arithmetic really issues"}
+            rooflines.append(roofline)
+        if timer_all is not None:
+            summ = timer_all.summary()
+
+            def top(prefix):
+                c = {k: v for k, v in summ.items() if k.startswith(prefix) and v["launches"]}
+                return max(c.items(), key=lambda kv: kv[1]["total_ms"]) if c else (None, None)
+            name, g = top("gemm_split")
+            if g:
+                ns = int(name.split("_")[1][5:])
+                mode, gu = GEMM_UNITS.get(ns, ("split", 3))
+                tf = g["units"] / g["total_ms"] / 1e9
+                rooflines.append({"bound": "mfma", "kernel": f"gemm_bf16_wfrag_kernel ({mode}), predictor GEMM "
+                                  f"{name.split('_')[2]} (M x N x K), the shape with the largest total time",
+                                  "achieved": round(tf, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tf / F16_MFMA_PEAK_TFLOPS, 4), "matrix_units_per_product": gu,
+                                  "frac_executed_mfma": round(gu * tf / F16_MFMA_PEAK_TFLOPS, 4),
+                                  "launches": g["launches"], "avg_launch_ms": round(g["total_ms"] / g["launches"], 4),
+                                  "traffic": None, "timed": "extra untimed pass, HIP events per launch"})
+            name, g = top("mha_")
+            if g:
+                tf = g["units"] / g["total_ms"] / 1e9
+                au = 3 if kernels._ATTN_QK16 else 1
+                apeak = F16_MFMA_PEAK_TFLOPS if kernels._ATTN_QK16 else FP32_MFMA_PEAK_TFLOPS
+                rooflines.append({"bound": "mfma", "kernel": f"mha_f32_kernel, predictor attention {name[4:]} "
+                                  f"(B x heads x Tq x Tk x dh), QK^T + PV", "achieved": round(tf, 2),
+                                  "peak": apeak, "unit": "TFLOP/s", "frac": round(tf / apeak, 4),
+                                  "matrix_units_per_product": au, "frac_executed_mfma": round(au * tf / apeak, 4),
+                                  "launches": g["launches"], "avg_launch_ms": round(g["total_ms"] / g["launches"], 4),
+                                  "traffic": None, "timed": "extra untimed pass, HIP events per launch"})
+            name, g = top("slot_attn_")
+            if g:
+                gbps = g["units"] / g["total_ms"] / 1e6
+                rooflines.append({"bound": "hbm", "kernel": f"slot_attn kernel(s) of one slot-attention iteration "
+                                  f"{name[10:]} (B x K x N x D): softmax over slots + weighted aggregation",
+                                  "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "launches": g["launches"],
+                                  "avg_launch_ms": round(g["total_ms"] / g["launches"], 4),
+                                  "bytes_per_launch": g["units"] / g["launches"],
+                                  "traffic": None, "timed": "extra untimed pass, HIP events per iteration; "
+                                  "algorithmic bytes = k and v (fp32) read once"})
+        m = all_metrics.mean(dim=(0, 1))
         line = {
             "metric": "predicted frames/sec (1 seed, 19 preds, 64x64, 30 slots)",
             "value": round(frames / elapsed, 2), "unit": "predicted frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ARITH.get((savi.decoder.conv_precision, pred.predictor.gemm_precision),
-                               f"decoder {savi.decoder.conv_precision} / predictor "
-                               f"{pred.predictor.gemm_precision}"),
+            "dtype": arithmetic_string(savi, pred, kernels),
             "data": "synthetic",
             "config": {"workload": "configs[1]: SAVi 30-slot 64x64 + TextOCVP_CustomTF predictor, "
                                    "1 seed + 19 preds (encode 20 frames, 19 rollout steps, "
                                    "decode 19 frames)",
                        "batch_per_gpu": B, "global_batch": B * world, "num_slots": NUM_SLOTS,
                        "num_preds": NUM_PREDS, "resolution": RES, "weights": "synthetic (synth.py)",
-                       "sharding": f"sequences x{world}, 1 all-gather of metrics"},
+                       "sharding": f"sequences x{world}, 1 all-gather of the (N, 19, 2) PSNR / SSIM rows"},
             "path_tflops": round(frames * PATH_GFLOP_PER_FRAME / 1e3 / elapsed, 2),
-            "mean_psnr": round(float(all_metrics.mean().item()), 3),
-            "roofline": roofline,
+            "mean_psnr": round(float(m[0].item()), 3), "mean_ssim": round(float(m[1].item()), 4),
+            "gathered_rows": int(all_metrics.shape[0]),
+            "roofline": roofline, "rooflines": rooflines,
         }
+        if extra:
+            line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            log(f"GPU: {line['value']} frames/s; timing the CPU oracle on one sequence ...")
+            log(f"GPU: {line['value']} frames/s; timing the CPU oracle (warm-up + 5 reps of 2 sequences) ...")
             line["cpu_baseline"] = cpu_baseline(savi, pred)
         print(json.dumps(line), flush=True)
     if world > 1:

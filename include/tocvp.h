@@ -233,6 +233,22 @@ int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const
                             const void* wf8, const float* bias, float* y, int nimg, int H, int W,
                             int Cin, int Cout, int relu, int layout, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Same convolution with SPLIT-fp16 operands ("f16x3", conv_f16x3.hip), the default decoder arithmetic:
+ * X = 2^8 x = Xh + Xl, W = 2^10 w = Wh + Wl in fp16 planes, product = Xl*Wh + Xh*Wl + Xh*Wh on the f16
+ * matrix cores (three v_mfma_f32_32x32x16_f16 into one fp32 accumulator): ~2^-21 per product, i.e.
+ * fp32-class.  Replaces nn.Conv2d(64,64,5,padding=2)+ReLU of ConvDecoder (decoders.py:96-110).
+ * Valid for |x| < 255 and |w| < 63 (operands saturate beyond).  in_mode / aux as tocvp_conv5x5_f32,
+ * layout as tocvp_conv5x5_f16f8_f32.
+ *   wf: fragment-order weight image written by tocvp_split_conv_weights_dec_f16x3, of
+ *   tocvp_conv_weights_dec_f16x3_bytes() bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_conv_weights_dec_f16x3_bytes(void);
+int tocvp_split_conv_weights_dec_f16x3(const float* w, void* wf, int Cout, int Cin, void* stream);
+int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf,
+                                const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
+                                int relu, int layout, void* stream);
+
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of
  *   w[co,ci,dy,dx];  w: (Cout,Cin,5,5), out: (25,Cout,Cin). */

@@ -497,15 +497,18 @@ def rollout(sd, slot_history, tokens, lengths, num_context, num_preds, buffer_si
 
 
 def forward_eval(savi_sd, pred_sd, videos, tokens, lengths, noise, num_context, num_preds,
-                 buffer_size=10):
+                 buffer_size=10, return_decode=False):
     """
     The three calls of Evaluator.forward_eval (05_evaluate_predictor.py:82-96) on CPU.
     Returns slot_history (B,T,K,D), pred_slots (B,P,K,D), pred_imgs (B,P,C,H,W) clamped to [0,1],
-    masks (B*P,K,1,H,W).
+    masks (B*P,K,1,H,W); with return_decode also {"recons_imgs" (unclamped), "recons"} of SAVi.decode.
     """
     B, L, C, H, W = videos.shape
     hist = savi_decomp(savi_sd, videos, noise, num_context + num_preds)
     preds = rollout(pred_sd, hist, tokens, lengths, num_context, num_preds, buffer_size)
     K, D = preds.shape[2:]
-    imgs, _, masks = savi_decode(savi_sd, preds.reshape(B * num_preds, K, D), (H, W), C)
-    return hist, preds, imgs.view(B, num_preds, C, H, W).clamp(0, 1), masks
+    imgs, recons, masks = savi_decode(savi_sd, preds.reshape(B * num_preds, K, D), (H, W), C)
+    out = (hist, preds, imgs.view(B, num_preds, C, H, W).clamp(0, 1), masks)
+    if return_decode:
+        out = out + ({"recons_imgs": imgs, "recons": recons},)
+    return out

@@ -64,7 +64,7 @@ def load_cfg(rel):
         return json.load(f)
 
 
-def build_reference(num_slots, num_context, num_preds, buffer_size=10, seed=0):
+def build_reference(num_slots, num_context, num_preds, buffer_size=10, seed=0, savi_family="damped"):
     """ SAVi + PredictorWrapper(TextOCVP_CustomTF) with synthetic weights, eval mode. """
     SAVi, TextOCVP_CustomTF, PredictorWrapper = import_reference()
     savi_cfg = load_cfg("models/SAVi.json")
@@ -86,7 +86,7 @@ def build_reference(num_slots, num_context, num_preds, buffer_size=10, seed=0):
                               "teacher_force": False, "input_buffer_size": buffer_size},
     }
     wrapper = PredictorWrapper(exp_params=exp_params, predictor=core).eval()
-    synth.fill_module_(savi, seed=seed, prefix="savi.")
+    synth.fill_module_(savi, seed=seed, prefix="savi.", family=savi_family)
     synth.fill_module_(wrapper, seed=seed, prefix="pred.")
     # the learned temporal PE is a plain attribute holding a Parameter (not in the state_dict
     # of every torch version): fill it explicitly so both sides agree.
@@ -225,6 +225,58 @@ def e2e_fixtures(out_dir):
              lengths=lengths.numpy(),
              masks_argmax_sub2=od["masks"].argmax(dim=1)[..., ::2, ::2].to(torch.uint8).numpy())
     print("e2e_c2:", sh.shape, ps.shape, pi.shape)
+
+
+@torch.no_grad()
+def parity_fixtures(out_dir):
+    """
+    Second and third weight family: the decoder arithmetic is qualified on
+    weights that do NOT attenuate pixel errors -- "undamped" (O(1) RGB head) and "xavier" (the
+    distribution of the reference's own _init_model) -- with FULL-RESOLUTION recons / masks / recons_imgs.
+    """
+    D = 128
+    fx = {}
+    for fam in ("undamped", "xavier"):
+        savi7, wrapper7 = build_reference(num_slots=7, num_context=1, num_preds=4, savi_family=fam)
+        dslots = synth.synth_tensor("unit.dec_slots", (2, 7, D), "normal")
+        out = savi7(mode="decode", slots=dslots)
+        fx[f"{fam}_dec7_recons_imgs"] = out["recons_imgs"].numpy()
+        fx[f"{fam}_dec7_recons"] = out["recons"].numpy()
+        fx[f"{fam}_dec7_masks"] = out["masks"].numpy()
+        # e2e config 1 (K=7, B=2, 1 seed + 4 preds, ragged captions) with this SAVi family
+        videos = synth.synth_videos(2, 5, seed=0)
+        tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+        noise = synth.synth_noise(2, 7, 128, seed=1)
+        sh, ps, pi, od = forward_eval(savi7, wrapper7, videos, tokens, lengths, noise, 1, 4)
+        fx[f"{fam}_c1_slot_history"] = sh.numpy()
+        fx[f"{fam}_c1_pred_slots"] = ps.numpy()
+        fx[f"{fam}_c1_recons_imgs"] = od["recons_imgs"].numpy()            # unclamped
+        fx[f"{fam}_c1_masks_s0"] = od["masks"][:4].numpy()                 # sample 0, 4 frames, full res
+        fx[f"{fam}_c1_recons_s0f3"] = od["recons"][3].numpy()
+        print(fam, "K=7 ranges: recons", float(out["recons"].min()), float(out["recons"].max()),
+              "masks max", float(out["masks"].max()), "slots |max|", float(ps.abs().max()))
+    np.savez(os.path.join(out_dir, "parity_k7.npz"), **fx)
+    print("parity_k7:", {k: v.shape for k, v in fx.items()})
+
+    fx = {}
+    savi30, wrapper30 = build_reference(num_slots=30, num_context=1, num_preds=19, savi_family="undamped")
+    dslots = synth.synth_tensor("unit.dec_slots30", (1, 30, D), "normal")
+    out = savi30(mode="decode", slots=dslots)
+    fx["undamped_dec30_recons_imgs"] = out["recons_imgs"].numpy()
+    fx["undamped_dec30_recons"] = out["recons"].numpy()
+    fx["undamped_dec30_masks"] = out["masks"].numpy()
+    # e2e config 2 (north star: K=30, B=1, 1 seed + 19 preds): rendered frames at full resolution,
+    # per-slot outputs of the LAST predicted frame at full resolution
+    videos = synth.synth_videos(1, 20, seed=0)
+    tokens, lengths = synth.synth_captions(1, max_len=12, seed=0)
+    noise = synth.synth_noise(1, 30, 128, seed=1)
+    sh, ps, pi, od = forward_eval(savi30, wrapper30, videos, tokens, lengths, noise, 1, 19)
+    fx["undamped_c2_recons_imgs"] = od["recons_imgs"].numpy()
+    fx["undamped_c2_masks_f18"] = od["masks"][18].numpy()
+    fx["undamped_c2_recons_f18"] = od["recons"][18].numpy()
+    fx["undamped_c2_masks_argmax"] = od["masks"].argmax(dim=1).to(torch.uint8).numpy()
+    np.savez(os.path.join(out_dir, "parity_k30.npz"), **fx)
+    print("parity_k30:", {k: v.shape for k, v in fx.items()})
 
 
 @torch.no_grad()
@@ -371,13 +423,15 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "uncond", "dinosaur", "t5", "train"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "uncond", "dinosaur", "t5", "train"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
         unit_fixtures(HERE)
     if "e2e" in what:
         e2e_fixtures(HERE)
+    if "parity" in what:
+        parity_fixtures(HERE)
     if "uncond" in what:
         uncond_fixtures(HERE)
     if "dinosaur" in what:

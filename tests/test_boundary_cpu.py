@@ -46,6 +46,8 @@ def test_checkpoint_roundtrip_and_prefix_shim(tmp_path):
     path = tmp_path / "checkpoint_epoch_final.pth"
     torch.save({"epoch": 3, "model_state_dict": savi.state_dict()}, path)
     other = load_checkpoint(str(path), setup_model(exp["model"]), only_model=True)
+    # freshly loaded weights are marked for one range-checked forward (no silent fp16-plane saturation)
+    assert other._range_unchecked and not savi._range_unchecked
     for (k, a), (_, b) in zip(savi.state_dict().items(), other.state_dict().items()):
         assert torch.equal(a, b), k
     # bare predictor checkpoint (keys without 'predictor.') loads into the wrapper
@@ -167,20 +169,33 @@ def test_precision_knobs(monkeypatch):
     assert knob("TOCVP_DECODER_PRECISION", "f16f8") == "bf16x3"
 
 
-def test_training_lr_schedule_matches_reference_shape():
-    """ linear warm-up to lr over warmup_steps (lib/schedulers.py:68-107), then CosineAnnealingLR(T_max, eta_min 1e-7)
-    (lib/setup_model.py:317-322) """
-    import math
+def test_training_lr_schedule_matches_reference_driver():
+    """
+    The LR of every optimiser step equals what the reference trainer sets: LRWarmUp + CosineAnnealingLR driven
+    by WarmupVSScehdule with the 0-based ``iter_`` BEFORE the step (base/basePredictorTrainer.py:280-286,
+    lib/schedulers.py:88-157; restated below from those lines, torch's own CosineAnnealingLR included).
+    """
     import types
     from textocvp_amd.train.step import PredictorTrainStep
+    for W, T in ((5, 40), (-1, 30)):
+        cfg = types.SimpleNamespace(lr=1e-4, warmup_steps=W if W > 0 else None, scheduler_steps=T, eta_min=1e-7)
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=1e-7)
+        active, final_step = True, -1
+        for iter_ in range(0, 30):
+            # WarmupVSScehdule.__call__ / LRWarmUp.__call__ / update_scheduler
+            if active:
+                if iter_ > W:
+                    final_step, active = iter_, False
+                elif iter_ >= 0:
+                    for g in opt.param_groups:
+                        g["lr"] = 1e-4 * (iter_ / W)
+            else:
+                sched.step()
+            used = opt.param_groups[0]["lr"]
+            assert PredictorTrainStep.lr_at(cfg, iter_) == pytest.approx(used, rel=1e-6, abs=1e-15), (W, iter_)
+            opt.step()                                    # keeps torch's scheduler-order warning quiet
     cfg = types.SimpleNamespace(lr=1e-4, warmup_steps=2000, scheduler_steps=1e6, eta_min=1e-7)
-    lr_at = lambda it: PredictorTrainStep.lr_at(cfg, it)
-    assert lr_at(1) == pytest.approx(1e-4 / 2000)
-    assert lr_at(1000) == pytest.approx(5e-5)
-    assert lr_at(2000) == pytest.approx(1e-4)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(
-        torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), T_max=1e6, eta_min=1e-7)
-    for t in (1, 500000, 1000000):
-        expect = 1e-7 + (1e-4 - 1e-7) * (1 + math.cos(math.pi * t / 1e6)) / 2
-        assert lr_at(2000 + t) == pytest.approx(expect, rel=1e-9)
-    assert sched.get_last_lr()[0] == pytest.approx(lr_at(2000))        # closed form of the torch scheduler at t = 0
+    assert PredictorTrainStep.lr_at(cfg, 0) == 0.0        # the reference's first step runs at lr = 0
+    assert PredictorTrainStep.lr_at(cfg, 2000) == pytest.approx(1e-4)
+    assert PredictorTrainStep.lr_at(cfg, 2001) == pytest.approx(1e-4)

@@ -392,8 +392,12 @@ def test_gemm_f16x3_range_behaviour(monkeypatch):
     assert (got[rows] - ref[rows]).abs().max().item() < 1e-5
     assert (got[3] - ref[3]).abs().max().item() < 400 * 0.1 * 4 * 2 ** -11
     monkeypatch.setattr(k, "_CHECK_RANGE", True)
-    with pytest.raises(k.TocvpError, match="out of range"):
+    with pytest.raises(k.TocvpRangeError, match="out of the fp16-plane range"):
         k.linear(x.to(DEV), w.to(DEV), precision="f16x3")
+    w_big = w.clone()
+    w_big[5, 5] = 64.0
+    with pytest.raises(k.TocvpRangeError, match="weight out of the fp16-plane range"):
+        k.linear(x[:3].contiguous().to(DEV), w_big.to(DEV), precision="f16x3")
     k.linear(x[:3].contiguous().to(DEV), w.to(DEV), precision="f16x3")
 
 
@@ -446,6 +450,73 @@ def test_conv5x5_f16f8_collapsed_input():
     err = (got.cpu().double() - ref).abs().max().item()
     print(f"f16f8 collapsed conv: max abs err {err:.3e} at scale {ref.abs().max().item():.3g}")
     assert err < 8e-5 * ref.abs().max().item()
+
+
+def _to_pass_major(x):
+    """ NHWC (n, H, W, 64) -> the pass-major layout (n, 4, H, W, 16) stored in a (n, H, W, 64) buffer """
+    n, H, W, C = x.shape
+    return x.reshape(n, H, W, 4, 16).permute(0, 3, 1, 2, 4).contiguous().reshape(n, H, W, C)
+
+
+@pytest.mark.parametrize("n", [3, 37])
+def test_conv5x5_dec_f16x3_is_fp32_class(n):
+    """ default decoder conv (3 fp16 products): as accurate as the exact-fp32 MFMA kernel, every layout """
+    k = _k()
+    x = rnd("bx", (n, 64, 64, 64))
+    x[0, :4, :4] = 0.0                                   # exact zeros, tiny and large activations
+    x[0, 5, 5, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 1e-3, 40.0, -90.0, 200.0, 0.25])
+    x[1] = x[1] * 1e-3                                   # a whole image of small activations
+    w = rnd("bw", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("bb", (64,), "uniform", 0.1)
+    lin = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2).permute(0, 2, 3, 1)
+    ref = torch.relu(lin)
+    wf = k.split_conv_weights_dec_f16x3(w.to(DEV))
+    got = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=True)
+    got32 = k.conv5x5(x.to(DEV), k.pack_conv_weights(w.to(DEV)), b.to(DEV), relu=True)
+    err = (got.cpu().double() - ref).abs()
+    err32 = (got32.cpu().double() - ref).abs().max().item()
+    scale = ref[2:].abs().max().item()
+    print(f"f16x3 decoder conv: max abs err {err.max().item():.3e} (fp32 MFMA {err32:.3e}) at scale {scale:.3g}; "
+          f"small image {err[1].max().item():.3e}")
+    assert err.max().item() < max(2.5 * err32, 2e-6 * scale)
+    assert err[1].max().item() < 3e-6                    # relative accuracy at the small image's own scale
+    got_lin = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=False)
+    assert (got_lin.cpu().double() - lin).abs().max().item() < max(2.5 * err32, 2e-6 * lin.abs().max().item())
+    # pass-major input / output: same values, other layout
+    xpm = _to_pass_major(x).to(DEV)
+    for pm_in, pm_out in ((True, False), (False, True), (True, True)):
+        y = k.conv5x5_dec_f16x3(xpm if pm_in else x.to(DEV), wf, b.to(DEV), relu=True, pm_in=pm_in, pm_out=pm_out)
+        want = _to_pass_major(got.cpu()) if pm_out else got.cpu()
+        assert torch.equal(y.cpu(), want), (pm_in, pm_out)
+
+
+def test_conv5x5_dec_f16x3_collapsed_input_and_range():
+    """ layer-1 mode of the default decoder conv + the weight range check at split time """
+    k = _k()
+    n, D, C0 = 6, 128, 64
+    slots = rnd("dslots", (n, D))
+    pw, pb = rnd("dpw", (D, 4, 1, 1)), rnd("dpb", (D,))
+    w0 = rnd("dw0", (C0, D, 5, 5), "uniform", (25 * D) ** -0.5)
+    b0 = rnd("db0", (C0,), "uniform", 0.1)
+    w1 = rnd("dw1", (64, C0, 5, 5), "uniform", (25 * C0) ** -0.5)
+    b1 = rnd("db1", (64,), "uniform", 0.1)
+    pos = O.soft_pos_embed(pw, pb, (64, 64))
+    x0 = (slots[:, None, None, :] + pos[None]).permute(0, 3, 1, 2)
+    a0 = torch.relu(F.conv2d(x0.double(), w0.double(), b0.double(), padding=2))
+    ref = torch.relu(F.conv2d(a0, w1.double(), b1.double(), padding=2)).permute(0, 2, 3, 1)
+    pos_d = k.pos_embed(pw.to(DEV), pb.to(DEV), 64, 64)
+    cpos = k.conv5x5(pos_d[None].contiguous(), k.pack_conv_weights(w0.to(DEV)), b0.to(DEV), relu=False)[0]
+    tapsum = k.dec_tapsum(w0.to(DEV))
+    S = k.linear(slots.to(DEV), tapsum.reshape(25 * C0, D)).reshape(n, 25, C0)
+    got = k.conv5x5_dec_f16x3(None, k.split_conv_weights_dec_f16x3(w1.to(DEV)), b1.to(DEV), relu=True,
+                              collapsed=(cpos.contiguous(), S.contiguous()))
+    err = (got.cpu().double() - ref).abs().max().item()
+    print(f"f16x3 collapsed conv: max abs err {err:.3e} at scale {ref.abs().max().item():.3g}")
+    assert err < 3e-6 * ref.abs().max().item()
+    w_big = w1.clone()
+    w_big[3, 5, 2, 2] = 70.0
+    with pytest.raises(k.TocvpError, match="weight out of the fp16-plane range"):
+        k.split_conv_weights_dec_f16x3(w_big.to(DEV))
 
 
 @pytest.mark.parametrize("M", [333, 5003])

@@ -69,3 +69,46 @@ def test_psnr_definition():
     a = torch.zeros(1, 1, 3, 4, 4)
     b = torch.full((1, 1, 3, 4, 4), 0.1)
     assert abs(psnr_per_frame(a, b).item() - 10 * torch.log10(torch.tensor(1 / (0.01 + 1e-8))).item()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N without torchrun: the launcher that replaces nn.DataParallel (baseEvaluator.py:142-145)
+# ---------------------------------------------------------------------------------------------------
+def _bench_module():
+    import importlib.util
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launcher_argument_to_children_env():
+    """ --gpus N -> N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, same argv, no exec """
+    bench = _bench_module()
+    env = bench.worker_env(3, 8, 29512, base={"PATH": "/bin", "WORLD_SIZE": "junk"})
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29512"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin"
+
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            started.append((cmd, env))
+            self.rc = 0 if env["RANK"] != "2" else 7
+
+        def wait(self):
+            return self.rc
+
+    rc = bench.launch_workers(4, argv=["--gpus", "4", "--steps", "2"], device_count=8,
+                              popen=lambda cmd, env: FakeProc(cmd, env))
+    assert rc == 7                                                 # a failing rank fails the launcher
+    assert [e["RANK"] for _, e in started] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" for _, e in started)
+    assert len({e["MASTER_PORT"] for _, e in started}) == 1
+    assert all(cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "2"] for cmd, _ in started)
+    # fewer devices than ranks: refuse, start nothing
+    started.clear()
+    assert bench.launch_workers(8, argv=[], device_count=1, popen=lambda cmd, env: FakeProc(cmd, env)) != 0
+    assert started == []

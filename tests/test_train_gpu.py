@@ -448,7 +448,10 @@ def test_graph_replayed_steps_equal_eager_steps():
         assert a["lr"] == b["lr"]
     assert res[0][0][0]["loss"] != res[0][0][2]["loss"]                       # the weights really moved
     for n in res[0][1]:
-        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 2e-6, n     # three steps of at most lr = 1e-4
+        # three steps of at most lr = 1e-4.  Not bit-identical: two float-atomic reductions in the backward pass
+        # make gradients reproducible to ~1e-10, and Adam turns a near-zero gradient g into lr * g / (|g| + eps),
+        # i.e. amplifies that by lr / eps = 1e4 on the few elements whose gradient vanishes
+        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 1e-5, n
 
 
 @pytest.mark.parametrize("M,N,Kd,tA,tB,ld_pad", [(70, 50, 33, False, False, 0), (64, 64, 64, True, False, 0),

@@ -38,15 +38,30 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, procs = [], []
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    hdr_m = max(os.path.getmtime(h) for h in headers)
+    jobs = int(os.environ.get("TOCVP_BUILD_JOBS", "4"))
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
+        objs.append(obj)
+        # per-object incremental rebuild: a source newer than its object, or any header newer than it
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_m):
+            continue
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-comment",
                f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        while sum(p.poll() is None for _, p in procs) >= jobs:
+            procs[0][1].wait() if procs[0][1].poll() is None else None
+            for _, p in procs:
+                if p.poll() is None:
+                    p.wait()
+                    break
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))

@@ -1,0 +1,285 @@
+// Decoder 5x5 convolution (64 -> 64 channels), SPLIT-fp16 operands ("f16x3"), fp32-class results.
+//
+// Replaces nn.Conv2d(64, 64, 5, padding=2) + ReLU of the reference's ConvDecoder
+// (models/EncodersDecoders/decoders.py:96-110) for layers 1..3 of the spatial-broadcast decoder.
+//
+// Each fp32 operand is scaled by an exact power of two (X = 2^8 x, W = 2^10 w; the scale keeps the
+// low plane out of the fp16 subnormals, which the matrix core flushes) and split into two fp16 planes
+//     X = Xh + Xl,  Xh = f16(X), Xl = f16(X - Xh)       (22 significant bits together)
+//     W = Wh + Wl
+// The product is evaluated as  Xl Wh + Xh Wl + Xh Wh  (Xl Wl ~ 2^-22 dropped) by three
+// v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: ~2^-21 per product, i.e. fp32-class, where the
+// f16 + e4m3 hybrid of conv_f16f8.hip leaves ~2^-15 (it failed the 1e-4 bar on weights with an O(1)
+// RGB head: profiles/r02_parity_by_mode.md).  Valid for |x| < 255, |w| < 63 (saturating beyond).
+//
+// Geometry (that of conv_f16f8.hip): 8 x 64 pixel tile x 64 output channels per 4-wave workgroup;
+// every wave owns 2 rows x 64 pixels x 64 channels = 4 x 2 accumulator tiles (128 VGPRs), so one
+// weight fragment from L1/L2 feeds four pixel blocks.  Four passes of 16 input channels:
+// LDS image 12 x 68 pixels x 80 B ([16 f16 Xh | 16 f16 Xl | 16 B pad], conflict-free for
+// ds_read_b128) = 65 KB -> 2 workgroups per CU, one staging while the other multiplies.
+// Weights in MFMA-fragment order straight from L1/L2, one tap (4 KiB) ahead in registers; the 25
+// taps of a pass are fully unrolled (LDS offsets are immediates, no barrier inside a pass).
+// Per tap and wave: 12 ds_read_b128, 4 global 16-B loads, 24 MFMAs (768 matrix cycles).
+// fp32 NHWC (or the pass-major layout (n, 4, H, W, 16) between consecutive layers) in HBM.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+#ifndef TOCVP_ABLATE
+#define TOCVP_ABLATE 0      // timing experiments only: 1 no weight loads, 4 no LDS operand reads, 5 halo for pass 0 only
+#endif
+
+namespace {
+
+constexpr int ABL = TOCVP_ABLATE;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 64, IH = TH + 4, IW = TW + 4;
+constexpr int C = 64, CCH = 16, NPASS = 4, NTAP = 25;
+constexpr int ROWB = 80, OFF_LO = 32;
+constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
+constexpr float F16MAX = 65504.f;
+constexpr int FRAG = 1024;                    // one B fragment: 64 lanes x 16 B
+constexpr int TAP_BYTES = 4 * FRAG;           // [plane(h, l)][nb(2)]
+
+struct Args {
+    const float* x; const float* aux; const unsigned char* wf; const float* bias; float* y;
+    int nimg, H, W, relu;
+    int pm_in, pm_out;      // pass-major activation layout (n, 4, H, W, 16) instead of NHWC (n, H, W, 64)
+};
+
+__device__ __forceinline__ int border_class(int p, int n) {
+    return p < 2 ? p : (p >= n - 2 ? 4 - (n - 1 - p) : 2);
+}
+
+__device__ __forceinline__ float clampf(float v, float m) { return __builtin_amdgcn_fmed3f(v, -m, m); }
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
+    constexpr int NT = 256;
+    constexpr int SS = C + 4;                                       // padded floats per staged pixel
+    constexpr int STAGE_BYTES = 4 * 64 * SS * 4;                    // one 64-pixel row per wave
+    constexpr int LDS_BYTES = IH * IW * ROWB > STAGE_BYTES ? IH * IW * ROWB : STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    unsigned char* in_s = lds;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_x = p.W / TW, tiles = tiles_x * (p.H / TH);
+    const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+
+    // accumulator tile m = 2 * (row of the wave's pair) + (32-pixel half of the 64-pixel row)
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const char* const xbase = reinterpret_cast<const char*>(MODE == 0 ? p.x + (size_t)img * p.H * p.W * C : p.x);
+    const char* const abase = reinterpret_cast<const char*>(MODE == 1 ? p.aux + (size_t)img * 25 * C : p.x);
+
+    // LDS byte offset of the wave's accumulator tile m (tap (0,0), pixel l31, k-half h)
+    int a_off[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_off[m] = ((2 * wave + (m >> 1)) * IW + (m & 1) * 32 + l31) * ROWB + h * 16;
+
+    // B fragments of one tap: [plane][nb]; two register sets, tap t in set t & 1
+    f16x8 bw[2][2][2];
+    auto load_w = [&](int set, int q) {                            // q = pass * 25 + tap
+        const unsigned char* base = p.wf + (size_t)q * TAP_BYTES + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                bw[set][pl][n] = *reinterpret_cast<const f16x8*>(base + (pl * 2 + n) * FRAG);
+    };
+
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass > 0) __syncthreads();          // every wave is done reading the previous image
+        // ---- halo tile: fp32 -> (Xh | Xl) fp16 planes in LDS.  All global loads of a batch are issued
+        // back to back from clamped (always valid) addresses and only then converted.  An opaque copy of
+        // the thread index keeps the staging addresses per-pass temporaries (hoisted out of the pass
+        // loop they would be spilled next to the 128 accumulator registers).
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        constexpr int ITEMS = IH * IW * (CCH / 4);
+        constexpr int NBATCH = MODE == 1 ? 2 : 1, BIT = (ITEMS + NBATCH * NT - 1) / (NBATCH * NT);
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+            if (ABL == 5 && pass > 0) break;
+            f32x4 tv[BIT];
+            f32x4 ts[MODE == 1 ? BIT : 1];
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int i = min(tq + (bt * BIT + it) * NT, ITEMS - 1);
+                const int pix = i / (CCH / 4), c = pass * CCH + (i % (CCH / 4)) * 4;
+                const int iy = min(max(ty0 + pix / IW - 2, 0), p.H - 1);
+                const int ix = min(max(tx0 + pix % IW - 2, 0), p.W - 1);
+                const unsigned off = p.pm_in
+                    ? (unsigned)(((pass * p.H + iy) * p.W + ix) * CCH + (c - pass * CCH)) * 4u
+                    : (unsigned)((iy * p.W + ix) * C + c) * 4u;
+                tv[it] = *reinterpret_cast<const f32x4*>(xbase + off);
+                if (MODE == 1) {
+                    const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
+                    ts[it] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(cls * C + c) * 4u);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int i = tq + (bt * BIT + it) * NT;
+                if (i < ITEMS) {
+                    const int pix = i / (CCH / 4), c = (i % (CCH / 4)) * 4;   // channel inside the pass
+                    const int iy = ty0 + pix / IW - 2, ix = tx0 + pix % IW - 2;
+                    const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    f32x4 v = tv[it];
+                    if (MODE == 1) {
+                        v += ts[it];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+                    }
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float X = inside ? clampf(v[u] * SA, F16MAX) : 0.f;
+                        hi[u] = (_Float16)X;
+                        lo[u] = (_Float16)(X - (float)hi[u]);
+                    }
+                    unsigned char* dst = in_s + pix * ROWB + c * 2;
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    *reinterpret_cast<f16x4*>(dst + OFF_LO) = lo;
+                }
+            }
+        }
+        load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
+        __syncthreads();
+
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int cur = tap & 1;
+            // next tap's fragments (clamped at the last tap of the pass: a harmless re-load)
+            if (ABL != 1) load_w(cur ^ 1, pass * NTAP + (tap + 1 < NTAP ? tap + 1 : tap));
+            const int dy = ABL == 4 ? 0 : tap / 5, dx = ABL == 4 ? 0 : tap % 5;
+            const unsigned char* a_base = in_s + (dy * IW + dx) * ROWB;
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ah[m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m]);
+                al[m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m] + OFF_LO);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = mfma16(al[m], bw[cur][0][n], acc[m][n]);      // Xl Wh
+                    acc[m][n] = mfma16(ah[m], bw[cur][1][n], acc[m][n]);      // Xh Wl
+                    acc[m][n] = mfma16(ah[m], bw[cur][0][n], acc[m][n]);      // Xh Wh
+                }
+        }
+    }
+    __syncthreads();                            // the halo image is dead: reuse it as the store stage
+
+    // Epilogue through LDS, one 64-pixel output row of the wave at a time: the accumulator layout
+    // gives a lane one channel of 16 pixels; staged, every store instruction writes 1 KiB of
+    // contiguous output (4 pixels x 256 B NHWC, or 16 pixels x 64 B of one pass-major plane).
+    float* stage = reinterpret_cast<float*>(lds) + wave * (64 * SS);
+    constexpr float UNSCALE = 1.f / (SA * SW);
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float bv = p.bias[n * 32 + l31];
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[2 * r2 + xh][n][r] * UNSCALE + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    stage[(xh * 32 + acc_row(r, h)) * SS + n * 32 + l31] = v;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int oy = ty0 + 2 * wave + r2;
+        if (p.pm_out) {
+            float* ybase = p.y + (size_t)img * p.H * p.W * C;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int plane = it >> 2, px = (it & 3) * 16 + (lane >> 2), cq = (lane & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
+                *reinterpret_cast<f32x4*>(ybase + (((size_t)plane * p.H + oy) * p.W + tx0 + px) * CCH + cq) = v;
+            }
+        } else {
+            float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + tx0) * C;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = lane + 64 * it;
+                const int px = idx >> 4, c4 = (idx & 15) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
+                *reinterpret_cast<f32x4*>(yrow + (size_t)px * C + c4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// (64, 64, 5, 5) fp32 -> wf: [pass(4)][tap(25)][plane(Wh, Wl)][nb(2)][lane(64)][8 f16]
+// lane (c = l & 31, hh = l >> 5): output channel nb*32 + c, input channels pass*16 + 8 hh + j of the tap.
+__global__ __launch_bounds__(256) void split_conv_weights_dec_f16x3_kernel(const float* __restrict__ w,
+                                                                           _Float16* __restrict__ wf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // over 25 taps * 64 * 64
+    if (i >= NTAP * C * C) return;
+    const int ci = i % C, co = (i / C) % C, tap = i / (C * C);
+    const float Wv = clampf(w[((size_t)co * C + ci) * NTAP + tap] * SW, F16MAX);
+    const _Float16 hi = (_Float16)Wv;
+    const _Float16 lo = (_Float16)(Wv - (float)hi);
+    const int pass = ci / CCH, cc = ci % CCH, hh = cc >> 3, j = cc & 7;
+    const int nb = co >> 5, c = co & 31;
+    const size_t tapbase = ((size_t)pass * NTAP + tap) * 4;        // fragments of this (pass, tap)
+    wf[((tapbase + 0 * 2 + nb) * 64 + hh * 32 + c) * 8 + j] = hi;
+    wf[((tapbase + 1 * 2 + nb) * 64 + hh * 32 + c) * 8 + j] = lo;
+}
+
+}  // namespace
+
+extern "C" size_t tocvp_conv_weights_dec_f16x3_bytes(void) { return (size_t)NPASS * NTAP * TAP_BYTES; }
+
+extern "C" int tocvp_split_conv_weights_dec_f16x3(const float* w, void* wf, int Cout, int Cin, void* stream) {
+    TOCVP_CHECK_ARG(w && wf && Cout == C && Cin == C);
+    hipLaunchKernelGGL(split_conv_weights_dec_f16x3_kernel, dim3((NTAP * C * C + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<_Float16*>(wf));
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf,
+                                           const float* bias, float* y, int nimg, int H, int W, int Cin,
+                                           int Cout, int relu, int layout, void* stream) {
+    TOCVP_CHECK_ARG(layout >= 0 && layout <= 3 && !(in_mode == 1 && (layout & 1)));
+    TOCVP_CHECK_ARG(x && wf && bias && y);
+    TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
+    TOCVP_CHECK_ARG(Cin == C && Cout == C);
+    TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0 && (W % TW) == 0);
+    TOCVP_CHECK_ARG((size_t)nimg * (H / TH) * (W / TW) < 0x7fffffffu);
+    // the staging addresses are 32-bit byte offsets from the image base
+    TOCVP_CHECK_ARG((size_t)H * W * C * 4 < 0x7fffffffu);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(wf) || !tocvp_aligned16(y) || (aux && !tocvp_aligned16(aux)))
+        return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    Args a{x, aux, static_cast<const unsigned char*>(wf), bias, y, nimg, H, W, relu, layout & 1,
+           (layout >> 1) & 1};
+    const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_mode == 0)
+        hipLaunchKernelGGL(conv5x5_dec_f16x3_kernel<0>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv5x5_dec_f16x3_kernel<1>, grid, dim3(256), 0, s, a);
+    return tocvp_launch_status();
+}

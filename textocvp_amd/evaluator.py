@@ -31,10 +31,11 @@ def _side_stream(device):
 
 @torch.no_grad()
 def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overlap_decode=None,
-                 **others):
+                 _calibrating=False, **others):
     """
     videos (B, L, C, H, W) in [0,1]; ``others`` carries caption_tokens / caption_lengths
-    (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets, masks).
+    (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets, masks,
+    recons, recons_imgs).
 
     overlap_decode (default: env TOCVP_OVERLAP_DECODE = auto|1|0; auto = on below 96 sequences): frame t is decoded on a SECOND HIP stream
     as soon as rollout step t is enqueued.  The rollout is a chain of short dependent kernels that
@@ -44,6 +45,15 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     B, L, C, H, W = videos.shape
     if L < num_context + num_preds:
         raise ValueError(f"Seq. length {L} smaller that {num_context = } + {num_preds = }")
+    if not _calibrating and (getattr(decomp_model, "_range_unchecked", False)
+                             or getattr(predictor, "_range_unchecked", False)):
+        # freshly loaded weights: one checked pass on this batch; a module whose operands leave the
+        # fp16-plane range is moved to range-free arithmetic (never silent saturation)
+        import warnings
+        from .setup_model import calibrate_precision
+        changed = calibrate_precision(decomp_model, predictor, videos, num_context, num_preds, **others)
+        if changed:
+            warnings.warn(f"textocvp_amd: operands outside the fp16-plane range, arithmetic changed: {changed}")
     num_slots, slot_dim = decomp_model.num_slots, decomp_model.slot_dim
     out_model = decomp_model(mode="decomp", x=videos, num_imgs=num_context + num_preds,
                              decode=False, **others)
@@ -59,7 +69,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         out_dec = decomp_model(mode="decode",
                                slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
         pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
-        masks = out_dec["masks"]
+        masks, recons, recons_imgs = out_dec["masks"], out_dec["recons"], out_dec["recons_imgs"]
     else:
         main = torch.cuda.current_stream()
         side = _side_stream(slot_history.device)
@@ -78,10 +88,14 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
         masks = torch.stack([d["masks"] for d in per_step], dim=1)
         masks = masks.reshape(B * num_preds, *masks.shape[2:])
+        recons = torch.stack([d["recons"] for d in per_step], dim=1)
+        recons = recons.reshape(B * num_preds, *recons.shape[2:])
+        recons_imgs = imgs.reshape(B * num_preds, C, H, W)
         pred_imgs = imgs.clamp(0, 1)
     targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)
+    # recons / recons_imgs: SAVi.decode's per-slot and composited frames, (B*P, ...) and UNclamped
     return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,
-            "targets": targets, "masks": masks}
+            "targets": targets, "masks": masks, "recons": recons, "recons_imgs": recons_imgs}
 
 
 def psnr_per_frame(preds, targets, eps=1e-8):

@@ -113,6 +113,13 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv_weights_dec_f16x3_bytes": (ctypes.c_size_t, []),
+    "tocvp_split_conv_weights_dec_f16x3": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv5x5_dec_f16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
     "tocvp_bmm_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int,
@@ -199,6 +206,18 @@ class TocvpError(RuntimeError):
     pass
 
 
+class TocvpRangeError(TocvpError):
+    """
+    An operand left the range of an fp16-plane arithmetic (|activation| < 255, |weight| < 63).
+    ``owner`` = (module, attribute name) of the arithmetic knob that governs the failing call (set by
+    the modules through ``range_owner`` / ``gemm_precision(owner=...)``), or None.
+    """
+
+    def __init__(self, msg, owner=None):
+        super().__init__(msg)
+        self.owner = owner
+
+
 class LaunchTimer:
     """
     Optional per-launch device timing of selected kernels with HIP events recorded on the stream
@@ -206,10 +225,14 @@ class LaunchTimer:
     launch duration of the dominant kernel inside the timed region; it is off by default.
     """
 
-    def __init__(self):
+    def __init__(self, only=("conv5x5",)):
         self.records = {}          # name -> list of (start_event, stop_event, work_units)
+        self.only = tuple(only)    # name prefixes that are timed (events perturb short kernels: keep the
+                                   # timed region of bench.py to the dominant kernel, time the rest apart)
 
     def wrap(self, name, units, fn):
+        if not name.startswith(self.only):
+            return fn()
         start = torch.cuda.Event(enable_timing=True)
         stop = torch.cuda.Event(enable_timing=True)
         start.record()
@@ -227,7 +250,11 @@ class LaunchTimer:
         return out
 
 
-TIMER = None   # set to a LaunchTimer() to time conv launches
+TIMER = None   # set to a LaunchTimer() to time launches (conv5x5_*, gemm_*, mha_*, slot_attn_*)
+
+
+def _timed(name, units, fn):
+    return fn() if TIMER is None else TIMER.wrap(name, units, fn)
 
 
 def lib():
@@ -278,22 +305,63 @@ _NSPLIT = {"bf16x3": 2, "bf16x6": 3, "f16x3": 22}     # 22 = two fp16 planes
 _SPLIT_CACHE = {}
 
 
-class gemm_precision:
-    """ context manager selecting the arithmetic of ``linear`` calls issued inside it """
+_RANGE_OWNER = None          # (module, attr) whose arithmetic knob governs the kernels launched right now
 
-    def __init__(self, mode):
-        if mode not in ("fp32", "bf16x3", "bf16x6", "f16x3"):
-            raise ValueError(f"unknown GEMM precision {mode!r}")
-        self.mode = mode
+
+class range_owner:
+    """ context manager: range errors raised inside name ``(module, attr)`` as the knob to change """
+
+    def __init__(self, module, attr):
+        self.owner = (module, attr)
 
     def __enter__(self):
-        global _GEMM_PRECISION
-        self.prev, _GEMM_PRECISION = _GEMM_PRECISION, self.mode
+        global _RANGE_OWNER
+        self.prev, _RANGE_OWNER = _RANGE_OWNER, self.owner
         return self
 
     def __exit__(self, *a):
-        global _GEMM_PRECISION
-        _GEMM_PRECISION = self.prev
+        global _RANGE_OWNER
+        _RANGE_OWNER = self.prev
+
+
+class check_range:
+    """ context manager: every fp16-plane kernel launched inside verifies its operands (slow: syncs) """
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _CHECK_RANGE
+        self.prev, _CHECK_RANGE = _CHECK_RANGE, self.on
+        return self
+
+    def __exit__(self, *a):
+        global _CHECK_RANGE
+        _CHECK_RANGE = self.prev
+
+
+class gemm_precision:
+    """
+    context manager selecting the arithmetic of ``linear`` calls issued inside it; ``owner`` =
+    (module, attr) of the knob the mode came from (named by range errors, see TocvpRangeError)
+    """
+
+    def __init__(self, mode, owner=None):
+        if mode not in ("fp32", "bf16x3", "bf16x6", "f16x3"):
+            raise ValueError(f"unknown GEMM precision {mode!r}")
+        self.mode, self.owner = mode, owner
+
+    def __enter__(self):
+        global _GEMM_PRECISION, _RANGE_OWNER
+        self.prev, _GEMM_PRECISION = _GEMM_PRECISION, self.mode
+        self.prev_owner = _RANGE_OWNER
+        if self.owner is not None:
+            _RANGE_OWNER = self.owner
+        return self
+
+    def __exit__(self, *a):
+        global _GEMM_PRECISION, _RANGE_OWNER
+        _GEMM_PRECISION, _RANGE_OWNER = self.prev, self.prev_owner
 
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
@@ -303,11 +371,25 @@ F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
 _CHECK_RANGE = os.environ.get("TOCVP_CHECK_RANGE", "0") != "0"
 
 
-def _check_f16_range(amax, what):
-    """ TOCVP_CHECK_RANGE=1: the fp16-plane arithmetic saturates silently at |x| = 255.9 """
-    if amax >= F16X3_ACT_RANGE:
-        raise TocvpError(f"{what} out of the fp16-plane range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}); "
-                         f"select the bf16 / fp32 arithmetic for this model")
+def _check_f16_range(amax, what, owner=None):
+    """ checked pass (TOCVP_CHECK_RANGE=1 / check_range()): the fp16-plane arithmetic saturates at |x| = 255.9 """
+    if not amax < F16X3_ACT_RANGE:                          # also trips on NaN
+        raise TocvpRangeError(
+            f"{what} out of the fp16-plane range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}); "
+            f"select the bf16 / fp32 arithmetic for this model (setup_model.calibrate_precision)",
+            owner if owner is not None else _RANGE_OWNER)
+
+
+def _check_f16_weight_range(w, what):
+    """ |w| < 63 for an fp16-plane weight image; skipped while a HIP graph is being captured (no sync there) """
+    if torch.cuda.is_current_stream_capturing():
+        return
+    wmax = float(w.abs().max())
+    if not wmax < F16X3_WEIGHT_RANGE:
+        raise TocvpRangeError(
+            f"{what} weight out of the fp16-plane range: |w| max {wmax:.4g} (< {F16X3_WEIGHT_RANGE}); "
+            f"select the bf16 / fp32 arithmetic for this model (setup_model.calibrate_precision)",
+            _RANGE_OWNER)
 
 
 class SplitAct:
@@ -414,18 +496,18 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         out = _alloc_planes(M, nsplit, N, w.device)
     elif out is None:
         out = torch.empty((M, N), device=w.device, dtype=torch.float32)
-    if frag_ok and nsplit == 22 and _CHECK_RANGE and not pre_split:
-        amax, wmax = float(x2.abs().max()), float(w.abs().max())
-        if amax >= F16X3_ACT_RANGE or wmax >= F16X3_WEIGHT_RANGE:
-            raise TocvpError(f"f16x3 operand out of range: |x| max {amax:.4g} (< {F16X3_ACT_RANGE}), "
-                             f"|w| max {wmax:.4g} (< {F16X3_WEIGHT_RANGE}); use precision='bf16x6'")
+    if frag_ok and nsplit == 22 and _CHECK_RANGE:
+        if not pre_split:
+            _check_f16_range(float(x2.abs().max()), f"f16x3 GEMM ({M}x{N}x{K}) activation")
+        _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
     if frag_ok:
         ws = _split_weight(w, nsplit, frag=True)
-        _check(lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,
-                                              _ptr(bias), _ptr(r2), N, _ptr(rowvec), int(rv_div),
-                                              int(rv_mod), int(bool(rv_flip)), _ptr(out),
-                                              int(bool(out_split)), N, M, N, K, int(act), _stream()),
-               "tocvp_gemm_bf16wfrag_f32")
+        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+            lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,
+                                           _ptr(bias), _ptr(r2), N, _ptr(rowvec), int(rv_div),
+                                           int(rv_mod), int(bool(rv_flip)), _ptr(out),
+                                           int(bool(out_split)), N, M, N, K, int(act), _stream()),
+            "tocvp_gemm_bf16wfrag_f32"))
     elif nsplit and K % 32 == 0:
         ws = _split_weight(w, nsplit)
         _check(lib().tocvp_gemm_bf16split_f32(_ptr(x2), K, _ptr(ws), nsplit, _ptr(bias), _ptr(r2), N,
@@ -504,10 +586,11 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
     if _ATTN_QK16 and _CHECK_RANGE:
         _check_f16_range(max(float(q.abs().max()), float(k.abs().max()), float(v.abs().max())),
-                         "attention q / k / v (f16x3 products)")
+                         "attention q / k / v (f16x3 products)", owner=("kernels", "_ATTN_QK16"))
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
-    _check(fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
-              dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32")
+    _timed(f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, lambda: _check(
+        fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
+           dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32"))
     return o
 
 
@@ -523,10 +606,12 @@ def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, device=q.device, dtype=torch.float32)
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
-    _check(lib().tocvp_slot_attn_iter_f32(_ptr(q), _ptr(k), _ptr(v), k.stride(1), _ptr(upd),
-                                          _ptr(attn_out), B, Ks, N, D, float(scale), float(eps),
-                                          _ptr(ws), ws.numel() * 4, _stream()),
-           "tocvp_slot_attn_iter_f32")
+    # units = algorithmic HBM bytes: k and v read once (B * 2 * N * D * sizeof)
+    _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
+        lib().tocvp_slot_attn_iter_f32(_ptr(q), _ptr(k), _ptr(v), k.stride(1), _ptr(upd),
+                                       _ptr(attn_out), B, Ks, N, D, float(scale), float(eps),
+                                       _ptr(ws), ws.numel() * 4, _stream()),
+        "tocvp_slot_attn_iter_f32"))
     return upd
 
 
@@ -583,6 +668,7 @@ def conv5x5(x, wp, bias, relu=True, out=None, precision="fp32"):
     split = precision == "f16x3" and Cin % 32 == 0 and Cout % 32 == 0 and H % 8 == 0
     if split and _CHECK_RANGE:
         _check_f16_range(float(x.abs().max()), "conv5x5 (f16x3) input")
+        _check_f16_weight_range(wp, "conv5x5 (f16x3)")
     def run():
         if split:
             _check(lib().tocvp_conv5x5_f16x3_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
@@ -731,6 +817,7 @@ def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=N
 def split_conv_weights_f16f8(w):
     """ (64, 64, 5, 5) fp32 -> (wf16, wf8) fragment-order weight images of the f16+fp8 hybrid conv """
     Cout, Cin = w.shape[:2]
+    _check_f16_weight_range(w, "decoder conv (f16f8)")
     wf16 = torch.empty(lib().tocvp_conv_weights_f16f8_bytes(0), device=w.device, dtype=torch.uint8)
     wf8 = torch.empty(lib().tocvp_conv_weights_f16f8_bytes(1), device=w.device, dtype=torch.uint8)
     _check(lib().tocvp_split_conv_weights_f16f8(_ptr(w.contiguous()), _ptr(wf16), _ptr(wf8), Cout, Cin,
@@ -757,8 +844,9 @@ def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None, pm_in=Fal
         xin, aux, mode, dev = x, None, 0, x.device
     wf16, wf8 = wimgs
     Cout = bias.shape[0]
-    if _CHECK_RANGE and mode == 0:
-        _check_f16_range(float(xin.abs().max()), "conv5x5_f16f8 input")
+    if _CHECK_RANGE:    # layer-1 mode: |relu(cpos + S[cls])| <= max|cpos| + max|S|
+        _check_f16_range(float(xin.abs().max()) + (float(aux.abs().max()) if mode == 1 else 0.0),
+                         "conv5x5_f16f8 input")
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
 
@@ -767,6 +855,52 @@ def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None, pm_in=Fal
                                              _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
                                              int(bool(relu)), int(bool(pm_in)) | (int(bool(pm_out)) << 1),
                                              _stream()), "tocvp_conv5x5_f16f8_f32")
+    if TIMER is not None:
+        TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
+    else:
+        run()
+    return out
+
+
+def split_conv_weights_dec_f16x3(w):
+    """ (64, 64, 5, 5) fp32 -> fragment-order [Wh | Wl] fp16 weight image of the f16x3 decoder conv """
+    Cout, Cin = w.shape[:2]
+    # checked once per weight version (the image is cached by the caller): saturation is never silent
+    _check_f16_weight_range(w, "decoder conv (f16x3)")
+    wf = torch.empty(lib().tocvp_conv_weights_dec_f16x3_bytes(), device=w.device, dtype=torch.uint8)
+    _check(lib().tocvp_split_conv_weights_dec_f16x3(_ptr(w.contiguous()), _ptr(wf), Cout, Cin, _stream()),
+           "tocvp_split_conv_weights_dec_f16x3")
+    return wf
+
+
+def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False):
+    """
+    64->64 5x5 conv with split-fp16 operands (tocvp_conv5x5_dec_f16x3_f32, fp32-class), fp32 in/out.
+    wf = split_conv_weights_dec_f16x3(weight); collapsed / pm_in / pm_out as conv5x5_f16f8.
+    """
+    if collapsed is not None:
+        cpos, S = collapsed
+        H, W, Cin = cpos.shape
+        n = S.shape[0]
+        assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
+        xin, aux, mode, dev = cpos, S, 1, cpos.device
+        if _CHECK_RANGE:    # |relu(cpos + S[cls])| <= max|cpos| + max|S|
+            _check_f16_range(float(cpos.abs().max()) + float(S.abs().max()), "conv5x5_dec_f16x3 layer-0 bound")
+    else:
+        n, H, W, Cin = x.shape
+        assert x.is_contiguous()
+        xin, aux, mode, dev = x, None, 0, x.device
+        if _CHECK_RANGE:
+            _check_f16_range(float(xin.abs().max()), "conv5x5_dec_f16x3 input")
+    Cout = bias.shape[0]
+    if out is None:
+        out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
+
+    def run():
+        _check(lib().tocvp_conv5x5_dec_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf), _ptr(bias), _ptr(out),
+                                                 n, H, W, Cin, Cout, int(bool(relu)),
+                                                 int(bool(pm_in)) | (int(bool(pm_out)) << 1), _stream()),
+               "tocvp_conv5x5_dec_f16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
     else:
@@ -802,6 +936,7 @@ def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
     y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
     if precision == "f16x3" and _CHECK_RANGE:
         _check_f16_range(float(x.abs().max()), "conv3x3 (f16x3) input")
+        _check_f16_weight_range(wp, "conv3x3 (f16x3)")
     fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
     _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
               int(bool(upsample2)), _stream()), "tocvp_conv3x3_" + precision)

@@ -6,7 +6,7 @@ Reference counterpart: models/Blocks/model_utils.py:66-79 (init_xavier_).
 import torch
 import torch.nn as nn
 
-__all__ = ["init_xavier_", "Derived", "require_inference"]
+__all__ = ["init_xavier_", "Derived", "require_inference", "RangeGuard"]
 
 
 @torch.no_grad()
@@ -39,6 +39,35 @@ class Derived:
             val = builder()
         self._store[key] = (sig, val)
         return val
+
+
+class RangeGuard:
+    """
+    Mixin of the top-level modules (SAVi, ExtendedDINOSAUR, PredictorWrapper).  The default arithmetic
+    splits operands into fp16 planes that are valid for |activation| < 255, |weight| < 63 and SATURATE
+    beyond.  Loading a state_dict marks the module unchecked; its next forward then runs with every
+    fp16-plane kernel verifying its operands (one slow pass) and raises ``kernels.TocvpRangeError``
+    naming the knob to change -- a checkpoint outside the range can never produce silently wrong
+    frames.  ``evaluator.forward_eval`` resolves the error by itself through
+    ``setup_model.calibrate_precision`` (moves the named module to range-free arithmetic).
+    """
+
+    def _init_range_guard(self):
+        self._range_unchecked = False
+        self.register_load_state_dict_post_hook(RangeGuard._mark_unchecked)
+
+    @staticmethod
+    def _mark_unchecked(module, incompatible_keys):
+        module._range_unchecked = True
+
+    def _guarded(self, fn, *args, **kwargs):
+        if not getattr(self, "_range_unchecked", False):
+            return fn(*args, **kwargs)
+        from ... import kernels as K
+        with K.check_range(True):
+            out = fn(*args, **kwargs)
+        self._range_unchecked = False
+        return out
 
 
 def require_inference(module):

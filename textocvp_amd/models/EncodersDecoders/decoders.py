@@ -62,11 +62,15 @@ class ConvDecoder(nn.Module):
         self.decoder = nn.Sequential(*mods)
         self._derived = Derived()
         self.max_slot_images = 2048          # slot images decoded per chunk (bounds HBM scratch)
-        # arithmetic of the 64->64 convs: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16 operands on
-        # the bf16 matrix cores, ~2^-16 per-product error, 5.3x fewer matrix cycles) or "f16f8"
-        # (f16 main product + two e4m3 cross products: 2/3 of the bf16x3 cycles, ~2.3x its error;
-        # needs W % 64 == 0, other shapes take the bf16x3 kernel)
-        self.conv_precision = knob("TOCVP_DECODER_PRECISION", "f16f8")
+        # arithmetic of the 64->64 convs:
+        #   "f16x3"  (default) split-fp16 operands, 3 f16 matrix products, ~2^-21 per product = fp32-class;
+        #            the only split mode that holds the 1e-4 bar with margin on weights with an O(1) RGB
+        #            head (profiles/r02_parity_by_mode.md).  Needs W % 64 == 0, H % 8 == 0 (else bf16x3).
+        #   "fp32"   exact fp32 MFMA;
+        #   "bf16x3" split-bf16 operands (~2^-16 per product), range-free;
+        #   "f16f8"  f16 main product + two e4m3 cross products (2/3 of the matrix cycles, ~2^-15 per
+        #            product): fastest, but beyond 1e-4 on recons / masks for un-damped heads -> opt-in.
+        self.conv_precision = knob("TOCVP_DECODER_PRECISION", "f16x3")
         self.pass_major = os.environ.get("TOCVP_CONV_PASS_MAJOR", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
@@ -89,6 +93,11 @@ class ConvDecoder(nn.Module):
         return self._derived.get(f"wh{i}", [conv.weight],
                                  lambda: K.split_conv_weights_f16f8(conv.weight))
 
+    def _split16(self, i):
+        conv = self.decoder[i].conv
+        return self._derived.get(f"w16{i}", [conv.weight],
+                                 lambda: K.split_conv_weights_dec_f16x3(conv.weight))
+
     def _collapsed_layer0(self, pos_table):
         """ (cpos (H,W,C0), tapsum (25*C0, D)) for the current weights / position table """
         c0 = self.decoder[0].conv
@@ -100,8 +109,14 @@ class ConvDecoder(nn.Module):
             return cpos, ts.reshape(25 * ts.shape[1], ts.shape[2])
         return self._derived.get("layer0", [c0.weight, c0.bias, pos_table], build)
 
+    range_fallbacks = {"conv_precision": {"f16x3": "bf16x3", "f16f8": "bf16x3"}}
+
     # -- forward -------------------------------------------------------------------------------
     def decode_slots(self, slots, pos_table):
+        with K.range_owner(self, "conv_precision"):
+            return self._decode_slots(slots, pos_table)
+
+    def _decode_slots(self, slots, pos_table):
         """
         slots (F, K, D), pos_table (H, W, D) -> recons_imgs (F,3,H,W), recons (F,K,3,H,W),
         masks (F,K,1,H,W)   (SAVi.decode, models/SAVi.py:241-261)
@@ -131,14 +146,19 @@ class ConvDecoder(nn.Module):
                     out = torch.empty((n, H, W, co), device=dev, dtype=torch.float32)
                     bufs[which] = out
                 c64 = conv.weight.shape[0] == 64 and conv.weight.shape[1] == 64
-                split = self.conv_precision in ("bf16x3", "f16f8") and c64
-                if self.conv_precision == "f16f8" and c64 and W % 64 == 0 and H % 8 == 0:
-                    # consecutive hybrid layers hand their activations over in the pass-major layout
+                split = self.conv_precision in ("bf16x3", "f16f8", "f16x3") and c64
+                if self.conv_precision in ("f16f8", "f16x3") and c64 and W % 64 == 0 and H % 8 == 0:
+                    # consecutive tiled layers hand their activations over in the pass-major layout
                     nxt = self.decoder[i + 1].conv if i + 1 < n_hidden else None
                     pm_out = self.pass_major and nxt is not None and tuple(nxt.weight.shape[:2]) == (64, 64)
-                    x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
-                                        collapsed=(cpos, S) if i == 1 else None,
-                                        pm_in=pm_prev, pm_out=pm_out)
+                    if self.conv_precision == "f16x3":
+                        x = K.conv5x5_dec_f16x3(x, self._split16(i), conv.bias, relu=True, out=out,
+                                                collapsed=(cpos, S) if i == 1 else None,
+                                                pm_in=pm_prev, pm_out=pm_out)
+                    else:
+                        x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
+                                            collapsed=(cpos, S) if i == 1 else None,
+                                            pm_in=pm_prev, pm_out=pm_out)
                     pm_prev = pm_out
                 elif split:
                     x = K.conv5x5_bf16x3(x, self._split(i), conv.bias, relu=True, out=out,
@@ -232,8 +252,14 @@ class MLPPatchDecoder(nn.Module):
         mods.append(nn.Conv2d(hidden_dim, 3, kernel_size=3, stride=1, padding=1))
         return nn.Sequential(*mods), ups
 
+    range_fallbacks = {"mlp_precision": {"f16x3": "fp32"}, "conv_precision": {"f16x3": "fp32"}}
+
     # -- image head on the kernels ---------------------------------------------------------------
     def _render(self, feats):
+        with K.range_owner(self, "conv_precision"):
+            return self._render_impl(feats)
+
+    def _render_impl(self, feats):
         """ feats (B, N, F) -> images (B, 3, S, S) """
         B = feats.shape[0]
         g = self.patch_grid[0]
@@ -280,7 +306,7 @@ class MLPPatchDecoder(nn.Module):
         linears = [m for m in self.mlp[i:] if isinstance(m, nn.Linear)]
         # 37 GFLOP per frame at config 4: f16x3 split operands (fp32-class) for the layers whose
         # shapes fit the fragment-order kernel; the 769-wide head stays on the exact fp32 MFMA
-        with K.gemm_precision(self.mlp_precision):
+        with K.gemm_precision(self.mlp_precision, owner=(self, "mlp_precision")):
             for j, lin in enumerate(linears[:-1]):
                 x = K.linear(x, lin.weight, lin.bias, act=K.ACT_RELU)
             # the head is out_dim = F + 1 wide (769): zero-padded to a multiple of 32 so that it runs

@@ -49,14 +49,17 @@ class SimpleConvEncoder(nn.Module):
         # convs 1..: "f16x3" (split fp16 operands on the f16 matrix cores, fp32-class) or "fp32" (exact MFMA)
         self.conv_precision = knob("TOCVP_ENCODER_PRECISION", "f16x3")
 
+    range_fallbacks = {"conv_precision": {"f16x3": "fp32"}}
+
     def forward_nhwc(self, x):
         """ x: (n, 3, H, W) view of contiguous image planes -> (n, H, W, C) """
         first = self.encoder[0].conv
         y = K.conv5x5_in3(x, first.weight, first.bias)
-        for i in range(1, len(self.encoder)):
-            conv = self.encoder[i].conv
-            wp = self._derived.get(f"wp{i}", [conv.weight], lambda c=conv: K.pack_conv_weights(c.weight))
-            y = K.conv5x5(y, wp, conv.bias, relu=True, precision=self.conv_precision)
+        with K.range_owner(self, "conv_precision"):
+            for i in range(1, len(self.encoder)):
+                conv = self.encoder[i].conv
+                wp = self._derived.get(f"wp{i}", [conv.weight], lambda c=conv: K.pack_conv_weights(c.weight))
+                y = K.conv5x5(y, wp, conv.bias, relu=True, precision=self.conv_precision)
         return y
 
     def forward(self, x):

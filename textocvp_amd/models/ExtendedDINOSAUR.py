@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import kernels as K
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
-from .Blocks.model_utils import init_xavier_, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, require_inference
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 
@@ -33,7 +33,7 @@ class _BackboneNotVendored(nn.Module):
             "as encoded_img_feats=(B, T, N, D) to forward_decomp")
 
 
-class ExtendedDINOSAUR(nn.Module):
+class ExtendedDINOSAUR(nn.Module, RangeGuard):
     def __init__(self, img_size, num_slots, slot_dim, num_iterations=1, num_iterations_first=3,
                  in_channels=3, mlp_hidden=128, mlp_encoder_dim=128, initializer=None, encoder=None,
                  decoder=None, transition_module=None, **kwargs):
@@ -60,12 +60,13 @@ class ExtendedDINOSAUR(nn.Module):
             dim_feats=slot_dim, dim_slots=slot_dim, num_slots=num_slots,
             num_iters_first=num_iterations_first, num_iters=num_iterations, mlp_hidden=mlp_hidden)
         self._init_model()
+        self._init_range_guard()
 
     def forward(self, mode="decomp", *args, **kwargs):
         if mode == "decomp":
-            return self.forward_decomp(*args, **kwargs)
+            return self._guarded(self.forward_decomp, *args, **kwargs)
         if mode == "decode":
-            return self.decode(*args, **kwargs)
+            return self._guarded(self.decode, *args, **kwargs)
         raise NameError(f"{mode = } not recognized. Use ['decomp', 'decode']")
 
     def forward_decomp(self, x=None, num_imgs=10, decode=True, encoded_img_feats=None, **kwargs):

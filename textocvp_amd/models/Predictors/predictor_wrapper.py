@@ -5,10 +5,12 @@ Autoregressive rollout wrapper.  Reference: models/Predictors/predictor_wrapper.
 import torch
 import torch.nn as nn
 
+from ..Blocks.model_utils import RangeGuard
+
 __all__ = ["PredictorWrapper"]
 
 
-class PredictorWrapper(nn.Module):
+class PredictorWrapper(nn.Module, RangeGuard):
     """
     Rolls a predictor out for ``num_preds`` steps over a sliding window of at most
     ``input_buffer_size`` frames, conditioned on the encoded caption (reference forward :50-87).
@@ -35,8 +37,13 @@ class PredictorWrapper(nn.Module):
         self.input_buffer_size = pp["input_buffer_size"]
         if self.input_buffer_size is None:
             self.input_buffer_size = self.num_context
+        self._init_range_guard()
 
     def forward(self, slot_history, num_preds=None, step_callback=None, **kwargs):
+        return self._guarded(self._rollout, slot_history, num_preds=num_preds,
+                             step_callback=step_callback, **kwargs)
+
+    def _rollout(self, slot_history, num_preds=None, step_callback=None, **kwargs):
         """
         slot_history (B, T, K, D) -> pred_slots (B, num_preds, K, D).
         ``step_callback(t, pred_t)`` (extension) is invoked right after step t is enqueued, so a

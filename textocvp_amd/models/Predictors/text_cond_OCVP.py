@@ -58,6 +58,8 @@ class BaseTextOCVP(nn.Module):
         self.gemm_precision = knob("TOCVP_PREDICTOR_PRECISION", "f16x3")
         self.last_layer_newest_frame_only = os.environ.get("TOCVP_LAST_LAYER_SUBSET", "1") != "0"
 
+    range_fallbacks = {"gemm_precision": {"f16x3": "bf16x6"}}
+
     def _instantiate_text_encoder(self):
         raise NotImplementedError("'BaseTextOCVP' does not implement '_instantiate_text_encoder'...")
 
@@ -66,7 +68,7 @@ class BaseTextOCVP(nn.Module):
         c = self._text_cache
         if c is not None and c[0] is text_embeddings and c[1] == text_embeddings._version:
             return c[2]
-        with K.gemm_precision(self.gemm_precision):
+        with K.gemm_precision(self.gemm_precision, owner=(self, "gemm_precision")):
             kv = [blk.cross_attention.project_text(text_embeddings) for blk in self.predictor]
         self._text_cache = (text_embeddings, text_embeddings._version, kv)
         return kv
@@ -77,7 +79,7 @@ class BaseTextOCVP(nn.Module):
         B, w, Ks, D = slots.shape
         slots = slots.contiguous()
         text_kv = self.prepare_text(text_embeddings)
-        with K.gemm_precision(self.gemm_precision):
+        with K.gemm_precision(self.gemm_precision, owner=(self, "gemm_precision")):
             tokens = K.linear(slots, self.mlp_in.weight, self.mlp_in.bias,
                               rowvec=self.pe.rows(w, slots.device), rv_div=Ks, rv_flip=True)
             tokens = tokens.reshape(B, w * Ks, self.token_dim)

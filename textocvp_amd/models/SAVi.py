@@ -15,7 +15,7 @@ from ..precision import knob
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
 from .Blocks.model_blocks import SoftPositionEmbed
-from .Blocks.model_utils import init_xavier_, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, require_inference
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 from .EncodersDecoders.encoders import get_encoder
@@ -23,7 +23,7 @@ from .EncodersDecoders.encoders import get_encoder
 __all__ = ["SAVi"]
 
 
-class SAVi(nn.Module):
+class SAVi(nn.Module, RangeGuard):
     """
     Same constructor kwargs (= keys of configs/models/SAVi.json), ``forward(mode=...)`` contract,
     output dictionaries, ``num_slots`` / ``slot_dim`` attributes and state_dict keys as the
@@ -55,6 +55,7 @@ class SAVi(nn.Module):
             dim_feats=mlp_encoder_dim, dim_slots=slot_dim, num_slots=num_slots,
             num_iters_first=num_iterations_first, num_iters=num_iterations, mlp_hidden=mlp_hidden)
         self._init_model()
+        self._init_range_guard()
         self.max_encode_images = 1024        # images encoded per chunk (bounds HBM scratch)
 
     def build_encoder(self, encoder_params):
@@ -76,11 +77,13 @@ class SAVi(nn.Module):
         self.decoder = get_decoder(in_channels=self.slot_dim, decoder=decoder_params)
 
     # ------------------------------------------------------------------------------------------
+    range_fallbacks = {"encoder_gemm_precision": {"f16x3": "fp32"}}
+
     def forward(self, mode="decomp", *args, **kwargs):
         if mode == "decomp":
-            return self.forward_decomp(*args, **kwargs)
+            return self._guarded(self.forward_decomp, *args, **kwargs)
         if mode == "decode":
-            return self.decode(*args, **kwargs)
+            return self._guarded(self.decode, *args, **kwargs)
         raise NameError(f"{mode = } not recognized. Use ['decomp', 'decode']")
 
     def forward_decomp(self, x, num_imgs=10, decode=True, **kwargs):
@@ -133,14 +136,14 @@ class SAVi(nn.Module):
         ln, l1, l2 = self.encoder_mlp[0], self.encoder_mlp[1], self.encoder_mlp[3]
         z = K.layer_norm(y.reshape(n * H * W, C), ln.weight, ln.bias, ln.eps,
                          add=self.encoder_pos_embedding.table().reshape(H * W, C))
-        with K.gemm_precision(self.encoder_gemm_precision):
+        with K.gemm_precision(self.encoder_gemm_precision, owner=(self, "encoder_gemm_precision")):
             z = K.linear(K.linear(z, l1.weight, l1.bias, act=K.ACT_RELU), l2.weight, l2.bias)
         return z.reshape(n, H * W, self.mlp_encoder_dim)
 
     def _encode_kv(self, imgs):
         """ image batch -> fused slot-attention keys/values (n, N, 2D) """
         feats = self._encode_feats(imgs)
-        with K.gemm_precision(self.encoder_gemm_precision):
+        with K.gemm_precision(self.encoder_gemm_precision, owner=(self, "encoder_gemm_precision")):
             return self.slot_attention.project_kv(feats)
 
     def encode(self, x):

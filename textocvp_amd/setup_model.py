@@ -138,53 +138,64 @@ def load_checkpoint(checkpoint_path, model, only_model=True, map_cpu=False, **kw
     if isinstance(model, ExtendedDINOSAUR):
         # the frozen timm ViT backbone is not vendored here: its weights are skipped
         sd = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
+    # load_state_dict marks the module "range-unchecked" (RangeGuard): its first forward verifies every
+    # fp16-plane operand and fails loudly (or forward_eval re-calibrates) instead of saturating silently
     model.load_state_dict(sd)
-    if not only_model:
-        raise NotImplementedError("optimizer / scheduler state is a training feature (not built)")
-    return model
+    if only_model:
+        return model
+    # training state, same tuple as the reference (lib/setup_model.py:228-240)
+    optimizer, scheduler = kwargs["optimizer"], kwargs.get("scheduler")
+    lr_warmup = kwargs.get("lr_warmup")
+    if hasattr(optimizer, "load_training_state"):
+        # textocvp_amd.train.PredictorTrainStep: Adam moments + step counter (schedule is a function of it)
+        optimizer.load_training_state(ckpt)
+        return model, optimizer, scheduler, lr_warmup, ckpt["epoch"] + 1
+    optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    if scheduler is not None and "scheduler_state_dict" in ckpt:
+        scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+    if lr_warmup is not None and "lr_warmup" in ckpt:
+        lr_warmup.load_state_dict(ckpt["lr_warmup"])
+    epoch = ckpt["epoch"] + 1
+    return model, optimizer, scheduler, lr_warmup, epoch
 
 
 def calibrate_precision(decomp_model, predictor, videos, num_context, num_preds, **others):
     """
     One checked pass over a representative batch that makes the fast arithmetic safe for a given
-    checkpoint.  The fp16-plane modes (f16x3 GEMMs / convs, f16f8 decoder convs) are fp32-class only
-    while |activation| < 255 and |weight| < 63 (operands saturate beyond); this runs the path once with
-    every such kernel checking its operands (kernels._CHECK_RANGE) and, where a check trips, moves the
-    owning module to the range-free arithmetic (decoder convs -> bf16x3, predictor GEMMs -> bf16x6,
-    encoder / DINOSAUR decoder -> fp32 MFMA, attention scores -> fp32 MFMA) and retries.  Returns {module: mode} of what was changed.
+    checkpoint.  The fp16-plane modes (f16x3 GEMMs / convs / attention products) are fp32-class only
+    while |activation| < 255 and |weight| < 63 (operands saturate beyond).  This runs the path once with
+    every such kernel verifying its operands; a ``kernels.TocvpRangeError`` names the arithmetic knob
+    (module, attribute) that governs the failing kernel, and exactly THAT module is moved to its
+    range-free arithmetic (``type(module).range_fallbacks``: decoder convs -> bf16x3, predictor GEMMs ->
+    bf16x6, encoder / DINOSAUR decoder -> fp32 MFMA, attention products -> fp32 MFMA), then the pass
+    is repeated.  Returns {(module class, attribute): new mode} of what was changed and clears the
+    modules' "unchecked" marks (models/Blocks/model_utils.py::RangeGuard).
     """
     from . import kernels as K
     from .evaluator import forward_eval
-    fallbacks = [
-        (getattr(decomp_model, "decoder", None), "conv_precision", {"f16f8": "bf16x3", "f16x3": "fp32"}),
-        (getattr(decomp_model, "decoder", None), "mlp_precision", {"f16x3": "fp32"}),
-        (getattr(predictor, "predictor", None), "gemm_precision", {"f16x3": "bf16x6"}),
-        (getattr(decomp_model, "encoder", None), "conv_precision", {"f16x3": "fp32"}),
-        (decomp_model, "encoder_gemm_precision", {"f16x3": "fp32"}),
-    ]
     changed = {}
-    prev, K._CHECK_RANGE = K._CHECK_RANGE, True
-    try:
-        for _ in range(len(fallbacks) + 1):
-            try:
+    for _ in range(16):
+        try:
+            with K.check_range(True):
                 forward_eval(decomp_model, predictor, videos, num_context, num_preds,
-                             overlap_decode=False, **others)
-                return changed
-            except K.TocvpError as err:
-                if "range" not in str(err):
-                    raise
-                if "attention" in str(err) and K._ATTN_QK16:
-                    K._ATTN_QK16 = False                     # process-wide: exact fp32 score products
-                    changed[("kernels", "_ATTN_QK16")] = False
-                    continue
-                for mod, attr, table in fallbacks:
-                    cur = getattr(mod, attr, None) if mod is not None else None
-                    if cur in table and (type(mod).__name__, attr) not in changed:
-                        setattr(mod, attr, table[cur])
-                        changed[(type(mod).__name__, attr)] = table[cur]
-                        break
-                else:
-                    raise
-        raise K.TocvpError("calibrate_precision: operands still out of range after every fallback")
-    finally:
-        K._CHECK_RANGE = prev
+                             overlap_decode=False, _calibrating=True, **others)
+            for m in (decomp_model, predictor):
+                if hasattr(m, "_range_unchecked"):
+                    m._range_unchecked = False
+            return changed
+        except K.TocvpRangeError as err:
+            owner = err.owner
+            if owner == ("kernels", "_ATTN_QK16") and K._ATTN_QK16:
+                K._ATTN_QK16 = False                     # process-wide: exact fp32 attention products
+                changed[("kernels", "_ATTN_QK16")] = False
+                continue
+            if owner is None:
+                raise
+            mod, attr = owner
+            table = getattr(type(mod), "range_fallbacks", {}).get(attr, {})
+            cur = getattr(mod, attr, None)
+            if cur not in table:
+                raise
+            setattr(mod, attr, table[cur])
+            changed[(type(mod).__name__, attr)] = table[cur]
+    raise K.TocvpError("calibrate_precision: operands still out of range after every fallback")

@@ -53,8 +53,45 @@ def synth_tensor(name, shape, kind="uniform", scale=1.0, seed=0):
     return torch.from_numpy(synth_array(name, shape, kind=kind, scale=scale, seed=seed))
 
 
-def _param_values(name, shape, seed):
-    """ Scaling rule per parameter name/shape (see module docstring). """
+FAMILIES = ("damped", "undamped", "xavier")
+
+
+def _xavier_values(name, shape, seed):
+    """
+    Family "xavier": the DISTRIBUTION of the reference's own initialisation (models/SAVi.py:279-293
+    ``_init_model`` -> ``init_xavier_``, Blocks/model_utils.py:66-79): xavier-uniform weights
+    (bound sqrt(6 / (fan_in + fan_out)), conv fans include the kernel area), zero biases, LayerNorm
+    gains 1, slot statistics U(+-sqrt(6 / (1 + D))) (initializers.py:80-83).  The reference draws
+    these from torch's global generator in module-construction order, which a name-keyed generator
+    cannot replay; what matters for parity is the scale of every tensor (O(1) RGB head, zero-centred
+    alpha), not the particular draw.  GRU weight_hh is xavier here (orthogonal in the reference).
+    """
+    last = name.split(".")[-1]
+    if "bias" in last:
+        return np.zeros(shape, dtype=np.float32)
+    if len(shape) == 1:
+        return np.ones(shape, dtype=np.float32)
+    if len(shape) == 3 and shape[0] == 1:
+        return synth_array(name, shape, "uniform", scale=math.sqrt(6.0 / (1 + shape[-1])), seed=seed)
+    rf = 1
+    for s in shape[2:]:
+        rf *= int(s)
+    fan_in, fan_out = int(shape[1]) * rf, int(shape[0]) * rf
+    return synth_array(name, shape, "uniform", scale=math.sqrt(6.0 / (fan_in + fan_out)), seed=seed)
+
+
+def _param_values(name, shape, seed, family="damped"):
+    """
+    Scaling rule per parameter name/shape (see module docstring).  ``family``:
+      "damped"    the round-1 weights: RGB rows of the decoder head scaled by 0.05 (pixels inside (0, 1));
+      "undamped"  the same weights with an O(1) RGB head (plain He-uniform rows, alpha row x2): pixel
+                  errors of the decoder arithmetic are NOT attenuated, rendered values leave [0, 1];
+      "xavier"    the distribution of the reference's own init (see _xavier_values).
+    """
+    if family not in FAMILIES:
+        raise ValueError(f"unknown weight family {family!r}")
+    if family == "xavier":
+        return _xavier_values(name, shape, seed)
     last = name.split(".")[-1]
     if name.endswith("pe.pe") or last == "pe":
         # learned temporal positional encoding, reference scale is token_dim ** -0.5
@@ -68,7 +105,8 @@ def _param_values(name, shape, seed):
         # RGB rows small (stay inside the clamp), alpha row large (sharp, informative masks)
         fan_in = int(shape[1] * shape[2] * shape[3])
         w = synth_array(name, shape, "uniform", scale=math.sqrt(6.0 / fan_in), seed=seed)
-        w[:-1] *= 0.05
+        if family == "damped":
+            w[:-1] *= 0.05
         w[-1:] *= 2.0
         return w
     if name.endswith("mlp_out.weight"):
@@ -93,7 +131,7 @@ def _param_values(name, shape, seed):
 
 
 @torch.no_grad()
-def fill_module_(module, seed=0, prefix=""):
+def fill_module_(module, seed=0, prefix="", family="damped"):
     """
     Overwrite every floating-point entry of ``module.state_dict()`` (parameters and buffers)
     plus known plain-attribute parameters with synthetic values keyed by their state_dict name.
@@ -104,7 +142,7 @@ def fill_module_(module, seed=0, prefix=""):
     for name, t in sd.items():
         if not torch.is_floating_point(t):
             continue
-        vals = _param_values(prefix + name, tuple(t.shape), seed)
+        vals = _param_values(prefix + name, tuple(t.shape), seed, family)
         t.copy_(torch.from_numpy(vals).to(t.dtype))
     return module
 
@@ -138,10 +176,10 @@ def synth_captions(batch, max_len=12, lengths=None, vocab_size=50, seed=0):
     return torch.from_numpy(tokens), torch.tensor([int(n) for n in lengths], dtype=torch.int64)
 
 
-def synth_state_dict(manifest, prefix="", seed=0):
+def synth_state_dict(manifest, prefix="", seed=0, family="damped"):
     """
     Build a reference-layout weight dict {name: CPU fp32 tensor} from a {name: shape} manifest
     (tests/golden/state_dict_manifest.json) without instantiating any module.
     """
-    return {name: torch.from_numpy(_param_values(prefix + name, tuple(shape), seed))
+    return {name: torch.from_numpy(_param_values(prefix + name, tuple(shape), seed, family))
             for name, shape in manifest.items()}

@@ -41,16 +41,25 @@ class PredictorTrainStep:
         self.w_img, self.w_slot = loss_weights
         self.warmup_steps, self.scheduler_steps, self.eta_min = warmup_steps, scheduler_steps, eta_min
         self.group = process_group
-        self.iteration = 0
-        self.state = {}                               # id(Var) -> (m, v)
+        self.iteration = 0                            # optimiser steps taken so far
+        self.state = {}                               # parameter name -> (exp_avg, exp_avg_sq)
 
     # ---------------------------------------------------------------------------------------
-    def lr_at(self, it):
-        """ linear warm-up to lr over warmup_steps, then CosineAnnealingLR(T_max=scheduler_steps, eta_min) """
-        if self.warmup_steps and it <= self.warmup_steps:
-            return self.lr * it / self.warmup_steps
-        t = it - (self.warmup_steps or 0)
-        return self.eta_min + (self.lr - self.eta_min) * (1.0 + math.cos(math.pi * t / self.scheduler_steps)) / 2.0
+    def lr_at(self, iter_):
+        """
+        Learning rate the reference trainer applies to the optimiser step of 0-based iteration ``iter_``
+        (base/basePredictorTrainer.py:280-286 calls WarmupVSScehdule BEFORE the step; lib/schedulers.py:
+        88-107, 140-157): lr * iter_ / warmup_steps while iter_ <= warmup_steps (so the very first step
+        runs at lr 0), lr at iter_ = warmup_steps + 1 (the warm-up object deactivates itself without
+        touching the optimiser), then one CosineAnnealingLR.step() per iteration:
+        eta_min + (lr - eta_min) (1 + cos(pi k / T_max)) / 2 with k = iter_ - warmup_steps - 1.
+        No warm-up is warmup_steps = -1 in the reference (lib/setup_model.py:356); None / 0 mean that here.
+        """
+        W = self.warmup_steps if self.warmup_steps and self.warmup_steps > 0 else -1
+        if iter_ <= W:
+            return self.lr * iter_ / W
+        k = iter_ - W - 1
+        return self.eta_min + (self.lr - self.eta_min) * (1.0 + math.cos(math.pi * k / self.scheduler_steps)) / 2.0
 
     @torch.no_grad()
     def _forward_backward(self, videos, caption_tokens, caption_lengths, others):
@@ -136,17 +145,20 @@ class PredictorTrainStep:
         return float(self._clip_scale()[1].item())
 
     def _hyper(self, it):
+        """ scalars of optimiser step number ``it`` (1-based): the reference's iter_ is it - 1 """
         b1, b2 = self.betas
-        return [self.lr_at(it), b1, b2, self.eps, 1.0 - b1 ** it, 1.0 - b2 ** it]
+        return [self.lr_at(it - 1), b1, b2, self.eps, 1.0 - b1 ** it, 1.0 - b2 ** it]
 
     def _optimizer_kernels(self):
         """ clip factor + Adam on every parameter, reading the step scalars from ``self._hyper_dev`` """
         clipn = self._clip_scale()
-        for v in self._grads():
-            st = self.state.get(id(v))
+        for name, v in self.model.names.items():
+            if v.grad is None:
+                v.grad = torch.zeros_like(v.data)
+            st = self.state.get(name)
             if st is None:
                 st = (torch.zeros_like(v.data), torch.zeros_like(v.data))
-                self.state[id(v)] = st
+                self.state[name] = st
             K._check(_L().tocvp_adam_f32(v.data.data_ptr(), v.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
                                          v.data.numel(), self._hyper_dev.data_ptr(), clipn.data_ptr(), _s()),
                      "tocvp_adam_f32")
@@ -160,6 +172,61 @@ class PredictorTrainStep:
         else:
             self._hyper_dev.copy_(host)
         return float(host[0])
+
+    # ---- checkpoint state, in the reference's formats (lib/setup_model.py:176-184, 228-240) --------------
+    def optimizer_state_dict(self):
+        """ torch.optim.Adam.state_dict() layout over PredictorWrapper.parameters() order """
+        names = list(self.model.names)
+        state = {}
+        for i, name in enumerate(names):
+            if name in self.state:
+                m, v = self.state[name]
+                state[i] = {"step": torch.tensor(float(self.iteration)), "exp_avg": m.clone(),
+                            "exp_avg_sq": v.clone()}
+        group = {"lr": self.lr_at(max(self.iteration - 1, 0)), "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "initial_lr": self.lr, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def scheduler_state_dict(self):
+        """ the CosineAnnealingLR fields the reference's checkpoint carries (steps taken after the warm-up) """
+        W = self.warmup_steps if self.warmup_steps and self.warmup_steps > 0 else -1
+        k = max(self.iteration - 1 - W - 1, 0)
+        return {"T_max": self.scheduler_steps, "eta_min": self.eta_min, "base_lrs": [self.lr], "last_epoch": k,
+                "_step_count": k + 1, "_last_lr": [self.lr_at(max(self.iteration - 1, 0))]}
+
+    def lr_warmup_state_dict(self):
+        """ LRWarmUp.state_dict() (lib/schedulers.py:109-114) """
+        W = self.warmup_steps if self.warmup_steps and self.warmup_steps > 0 else -1
+        active = self.iteration - 1 <= W
+        return {"init_lr": self.lr, "warmup_steps": W, "active": active, "final_step": -1 if active else W + 1}
+
+    def state_dict(self, epoch=0):
+        """ everything save_checkpoint stores (lib/setup_model.py:178-184) plus the exact step counter """
+        return {"epoch": epoch, "model_state_dict": self.wrapper.state_dict(),
+                "optimizer_state_dict": self.optimizer_state_dict(),
+                "scheduler_state_dict": self.scheduler_state_dict(), "lr_warmup": self.lr_warmup_state_dict(),
+                "iteration": self.iteration}
+
+    def load_training_state(self, ckpt):
+        """
+        Resume from ``state_dict()`` or from a checkpoint written by the reference trainer (its optimizer /
+        scheduler / lr_warmup entries; the step count then comes from Adam's per-parameter ``step``).
+        The model weights are loaded by setup_model.load_checkpoint.
+        """
+        opt = ckpt["optimizer_state_dict"]
+        names = list(self.model.names)
+        steps = 0
+        for i, st in opt["state"].items():
+            name = names[int(i)]
+            ref = self.model.names[name].data
+            m = st["exp_avg"].to(device=ref.device, dtype=torch.float32).reshape(ref.shape).contiguous().clone()
+            v = st["exp_avg_sq"].to(device=ref.device, dtype=torch.float32).reshape(ref.shape).contiguous().clone()
+            self.state[name] = (m, v)
+            steps = max(steps, int(float(st["step"])))
+        self.iteration = int(ckpt.get("iteration", steps))
+        self._graphs = None                                   # moments were re-allocated: re-capture
+        return self
 
     def apply(self):
         """ clip_grad_norm_ + Adam on every predictor parameter; returns (grad norm, lr used) """
