@@ -24,7 +24,7 @@ __all__ = [
     "layer_norm", "linear", "build_grid", "savi_encode", "slot_attention", "transition_block",
     "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
     "forward_eval", "sub", "uncond_step", "encoder_layer_prenorm", "sinusoid_pe",
-    "mlp_patch_decoder", "dinosaur_decomp", "t5_encoder",
+    "mlp_patch_decoder", "dinosaur_decomp", "t5_encoder", "vit_encoder", "IMAGENET_MEAN",
 ]
 
 
@@ -269,6 +269,51 @@ def mlp_patch_decoder(sd, slots, img_size, patch_size=14, num_layers_cnn=4):
     if y.shape[-1] != img_size:
         y = F.interpolate(y, size=(img_size, img_size), mode="bilinear", align_corners=False)
     return y, recons_feats, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT backbone of ExtendedDINOSAUR  (models/EncodersDecoders/timm_encoders.py:18-96)
+#
+# PARITY UNPINNED: the arithmetic lives in the third-party package `timm` (un-pinned in the reference's
+# environment.yml:24 and absent from this image), and the reference holds no test vector for it.  This
+# function restates timm's PUBLISHED VisionTransformer algorithm (timm/models/vision_transformer.py,
+# 0.9.x: PatchEmbed = Conv2d(k = s = patch) + flatten; _pos_embed = cat(cls_token, x) + pos_embed;
+# Block = x + ls1(attn(norm1(x))), x + ls2(mlp(norm2(x))) with LayerScale gamma, fused qkv Linear with
+# bias, softmax(q k^T / sqrt(dh)) v, exact-erf GELU MLP; `vit_base_patch14_dinov2`: patch 14, 768 wide,
+# 12 blocks, 12 heads, mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6, init_values 1e-5) as called by the
+# reference's wrapper: normalise, patch_embed, _pos_embed, patch_drop (identity), norm_pre (identity),
+# blocks, drop the class token.  The backbone's final `norm` is NOT applied (timm_encoders.py:64-69).
+# ------------------------------------------------------------------------------------------------
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # timm.data.IMAGENET_DEFAULT_MEAN = default_cfg["mean"] of the DINOv2 ViTs
+
+
+def vit_encoder(sd, imgs, patch=14, heads=12, eps=1e-6, num_blocks=None):
+    """
+    imgs (n, 3, H, W) in [0, 1] -> patch features (n, (H/patch)*(W/patch), E).  ``sd``: timm
+    VisionTransformer state_dict (keys below ``encoder.vit_backbone.``).
+    The wrapper divides by the MEAN, not the standard deviation (timm_encoders.py:54-56 sets
+    ``self.std`` from default_cfg["mean"]): reproduced.
+    """
+    mean = torch.tensor(IMAGENET_MEAN, dtype=imgs.dtype).view(1, 3, 1, 1)
+    x = (imgs - mean) / mean                                               # :88-96, std := mean
+    x = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
+    x = x.flatten(2).transpose(1, 2)                                       # (n, N, E)
+    n, N, E = x.shape
+    x = torch.cat([sd["cls_token"].expand(n, -1, -1), x], dim=1) + sd["pos_embed"]
+    i = 0
+    while f"blocks.{i}.norm1.weight" in sd and (num_blocks is None or i < num_blocks):
+        p = sub(sd, f"blocks.{i}.")
+        y = layer_norm(x, p["norm1.weight"], p["norm1.bias"], eps)
+        qkv = linear(y, p["attn.qkv.weight"], p["attn.qkv.bias"])
+        a = attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, (E // heads) ** -0.5)
+        a = linear(a, p["attn.proj.weight"], p["attn.proj.bias"])
+        x = x + (a * p["ls1.gamma"] if "ls1.gamma" in p else a)
+        y = layer_norm(x, p["norm2.weight"], p["norm2.bias"], eps)
+        y = linear(gelu(linear(y, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
+        x = x + (y * p["ls2.gamma"] if "ls2.gamma" in p else y)
+        i += 1
+    return x[:, 1:]
 
 
 def dinosaur_decomp(sd, feats, noise, iters_first=3, iters=1, trans_heads=4):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """
-Timing of BASELINE config 4 downstream of the ViT backbone: ExtendedDINOSAUR (24 slots, 224x224 ->
-256 patches of 768 features) + TextOCVP_T5, 1 seed + 29 preds.  Patch features are synthetic inputs
-(the timm backbone is not vendored).  Informational; the driver's bench line is bench.py (config 2).
+Timing of BASELINE config 4 FROM PIXELS: ExtendedDINOSAUR (DINOv2 ViT-B/14 backbone, 24 slots, 224x224 ->
+256 patches of 768 features) + TextOCVP_T5, 1 seed + 29 preds.  Informational; the driver's bench line is
+bench.py (config 2).
 """
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -15,18 +15,20 @@ exp = default_exp_params(num_slots=K, num_context=1, num_preds=P, predictor_name
 pred = setup_predictor(exp).eval()
 synth.fill_module_(model, prefix="dino."); synth.fill_module_(pred, prefix="pred.")
 model, pred = model.cuda(), pred.cuda()
-feats = synth.synth_tensor("c4.feats", (B, T, 256, 768), "normal").cuda()
+videos = synth.synth_videos(B, T, height=224, width=224, seed=4).cuda()
 ids = torch.randint(1, 32000, (B, 16), device="cuda"); mask = torch.ones(B, 16, dtype=torch.int64, device="cuda")
 noise = synth.synth_noise(B, K, 128, seed=3).cuda()
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
 with torch.no_grad():
     for it in range(2):
         t0 = sync()
+        feats = model.encoder(videos)
+        t05 = sync()
         hist = model(mode="decomp", num_imgs=T, decode=False, encoded_img_feats=feats, init_noise=noise)["slot_history"]
         t1 = sync()
         ps = pred(hist, caption_tokens=ids, attn_masks=mask)
         t2 = sync()
         out = model(mode="decode", slots=ps.reshape(B * P, K, 128))
         t3 = sync()
-        print(f"B={B} iter{it}: decomp(from feats) {t1-t0:.3f}s rollout {t2-t1:.3f}s decode {t3-t2:.3f}s "
+        print(f"B={B} iter{it}: ViT {t05-t0:.3f}s slots(from feats) {t1-t05:.3f}s rollout {t2-t1:.3f}s decode {t3-t2:.3f}s "
               f"total {t3-t0:.3f}s -> {B*P/(t3-t0):.1f} predicted frames/s", flush=True)

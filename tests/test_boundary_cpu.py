@@ -126,20 +126,37 @@ def test_unconditioned_predictor_layouts():
         pred(torch.zeros(1, 3, 7, 128))
 
 
-def test_dinosaur_layout_and_backbone_guard():
+def test_dinosaur_layout_and_vit_backbone_keys():
+    """ ExtendedDINOSAUR: decoder keys from the reference's manifest; encoder.vit_backbone.* follows timm's
+    published VisionTransformer names / shapes for vit_base_patch14_dinov2 at 224 px (timm is not importable
+    here, so this half of the layout is pinned by the literal list below, not by a captured manifest) """
     import json
     from textocvp_amd.setup_model import default_dinosaur_params
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest_dinosaur_decoder.json")))
     model = setup_model(default_dinosaur_params(num_slots=24, img_size=224))
-    got = {k[len("decoder."):]: list(v.shape) for k, v in model.state_dict().items()
-           if k.startswith("decoder.")}
+    sd = model.state_dict()
+    got = {k[len("decoder."):]: list(v.shape) for k, v in sd.items() if k.startswith("decoder.")}
     assert got == man
-    assert not any(k.startswith("encoder.") for k in model.state_dict())
     for k in ("linear_feat_proj.0.weight", "linear_feat_proj.3.bias", "slot_attention.to_q.weight",
               "initializer.slots_mu", "transition_module.attn.q.weight"):
-        assert k in model.state_dict(), k
-    with torch.no_grad(), pytest.raises(NotImplementedError):
-        model(mode="decomp", x=torch.zeros(1, 2, 3, 224, 224), num_imgs=2)    # ViT not vendored
+        assert k in sd, k
+    vit = {k[len("encoder.vit_backbone."):]: tuple(v.shape) for k, v in sd.items() if k.startswith("encoder.")}
+    expect = {"cls_token": (1, 1, 768), "pos_embed": (1, 257, 768), "patch_embed.proj.weight": (768, 3, 14, 14),
+              "patch_embed.proj.bias": (768,), "norm.weight": (768,), "norm.bias": (768,)}
+    for i in range(12):
+        b = f"blocks.{i}."
+        expect.update({b + "norm1.weight": (768,), b + "norm1.bias": (768,), b + "attn.qkv.weight": (2304, 768),
+                       b + "attn.qkv.bias": (2304,), b + "attn.proj.weight": (768, 768), b + "attn.proj.bias": (768,),
+                       b + "ls1.gamma": (768,), b + "norm2.weight": (768,), b + "norm2.bias": (768,),
+                       b + "mlp.fc1.weight": (3072, 768), b + "mlp.fc1.bias": (3072,),
+                       b + "mlp.fc2.weight": (768, 3072), b + "mlp.fc2.bias": (768,), b + "ls2.gamma": (768,)})
+    assert vit == expect
+    assert not any(p.requires_grad for p in model.encoder.parameters())          # frozen (ExtendedDINOSAUR.py:92)
+    from textocvp_amd import kernels
+    with torch.no_grad(), pytest.raises((kernels.TocvpError, RuntimeError)):
+        model(mode="decomp", x=torch.zeros(1, 2, 3, 224, 224), num_imgs=2)       # no CPU path
+    with torch.no_grad(), pytest.raises(ValueError):
+        model.encoder(torch.zeros(1, 3, 64, 64))                                # timm: input size must match
 
 
 def test_t5_predictor_layout():

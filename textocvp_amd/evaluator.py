@@ -69,7 +69,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         out_dec = decomp_model(mode="decode",
                                slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
         pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
-        masks, recons, recons_imgs = out_dec["masks"], out_dec["recons"], out_dec["recons_imgs"]
+        masks, recons, recons_imgs = out_dec["masks"], out_dec.get("recons"), out_dec["recons_imgs"]
     else:
         main = torch.cuda.current_stream()
         side = _side_stream(slot_history.device)
@@ -88,8 +88,10 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
         masks = torch.stack([d["masks"] for d in per_step], dim=1)
         masks = masks.reshape(B * num_preds, *masks.shape[2:])
-        recons = torch.stack([d["recons"] for d in per_step], dim=1)
-        recons = recons.reshape(B * num_preds, *recons.shape[2:])
+        recons = None
+        if "recons" in per_step[0]:              # SAVi; ExtendedDINOSAUR returns recons_feats instead
+            recons = torch.stack([d["recons"] for d in per_step], dim=1)
+            recons = recons.reshape(B * num_preds, *recons.shape[2:])
         recons_imgs = imgs.reshape(B * num_preds, C, H, W)
         pred_imgs = imgs.clamp(0, 1)
     targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)

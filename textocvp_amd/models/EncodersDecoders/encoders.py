@@ -21,8 +21,14 @@ def get_encoder(in_channels, encoder, **kwargs):
     if name == "ConvEncoder":
         return SimpleConvEncoder(in_channels=in_channels, hidden_dims=params.pop("num_channels"),
                                  kernel_size=params.pop("kernel_size"))
-    raise NotImplementedError(
-        f"encoder {name!r}: only 'ConvEncoder' is built so far (ViT backbones are SURVEY 8f rank 3)")
+    if name in ("vit_base_patch14_dinov2", "vit_small_patch14_dinov2"):
+        # reference encoders.py:77-95: timm factory + ViTEncoder wrapper; note that the reference reads
+        # 'num_blocks' (ExtendedDINOSAUR.json sets 'encoder_num_blocks', so all 12 blocks run: SURVEY 3.4)
+        from . import timm_encoders
+        factory = getattr(timm_encoders, name)
+        return timm_encoders.ViTEncoder(vit_backbone=factory(img_size=params.get("img_size")),
+                                        num_blocks=params.get("num_blocks"))
+    raise NotImplementedError(f"Unknown encoder {name}... (built: 'ConvEncoder', DINOv2 ViT-S/14 and ViT-B/14)")
 
 
 class SimpleConvEncoder(nn.Module):

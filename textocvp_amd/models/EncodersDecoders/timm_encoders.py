@@ -1,0 +1,212 @@
+"""
+DINOv2 ViT backbone of ExtendedDINOSAUR on the MI355X kernels.
+Reference: models/EncodersDecoders/timm_encoders.py (ViTEncoder :18-96, factories :215-267) wrapping
+timm's VisionTransformer.  timm is third-party and absent from this image: the arithmetic below follows
+timm's published VisionTransformer (PARITY UNPINNED; the test suite holds a CPU restatement of the same
+published algorithm),
+the parameter names are timm's, so a reference checkpoint's ``encoder.vit_backbone.*`` entries load strictly.
+
+    ViTEncoder.forward (timm_encoders.py:59-70):
+        normalize_images   (x - mean) / std with std := mean  (the reference's bug, :54-56, reproduced)
+        patch_embed        Conv2d(3, E, k = s = 14) + flatten          -> im2col (data movement) + GEMM
+        _pos_embed         cat(cls_token, x) + pos_embed               -> GEMM epilogue (row-periodic addend)
+        patch_drop, norm_pre                                           identity
+        blocks x 12        x + ls1 * proj(attn(norm1 x));  x + ls2 * fc2(gelu(fc1(norm2 x)))
+        x[:, 1:]           drop the class token   (the backbone's final ``norm`` is NOT applied)
+
+MI355X path: the normalisation is folded into the patch-embedding weights (exact algebra: (x - m) / m =
+x / m - 1), LayerScale gammas are folded into the proj / fc2 weights and biases, so every block is
+LayerNorm -> f16x3 GEMM (fused qkv, bias) -> fused attention kernel -> f16x3 GEMM (+ residual epilogue)
+-> LayerNorm -> f16x3 GEMM (+ GELU epilogue) -> f16x3 GEMM (+ residual epilogue): 43.6 GFLOP per frame.
+"""
+
+import torch
+import torch.nn as nn
+
+from ... import kernels as K
+from ...precision import knob
+from ..Blocks.model_utils import Derived
+
+__all__ = ["ViTEncoder", "VisionTransformer", "vit_base_patch14_dinov2", "vit_small_patch14_dinov2",
+           "IMAGENET_DEFAULT_MEAN"]
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)      # timm.data.constants, default_cfg["mean"] of the DINOv2 ViTs
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, 3 * dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init_values):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, init_values, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = _Attention(dim, num_heads, qkv_bias)
+        self.ls1 = _LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.ls2 = _LayerScale(dim, init_values) if init_values else nn.Identity()
+
+
+class VisionTransformer(nn.Module):
+    """
+    Parameter container with timm's VisionTransformer names (cls_token, pos_embed, patch_embed.proj,
+    blocks.N.{norm1, attn.qkv, attn.proj, ls1.gamma, norm2, mlp.fc1, mlp.fc2, ls2.gamma}, norm);
+    ``forward_features_no_norm`` is the sequence of sub-module calls the reference's wrapper makes.
+    """
+
+    def __init__(self, img_size=224, patch_size=14, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4, qkv_bias=True, init_values=1e-5, eps=1e-6, **kwargs):
+        super().__init__()
+        if img_size % patch_size:
+            raise ValueError(f"{img_size = } is not a multiple of {patch_size = }")
+        self.img_size, self.patch_size, self.embed_dim, self.num_heads = img_size, patch_size, embed_dim, num_heads
+        self.num_patches = (img_size // patch_size) ** 2
+        self.default_cfg = {"mean": IMAGENET_DEFAULT_MEAN, "std": (0.229, 0.224, 0.225)}
+        self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, self.num_patches + 1, embed_dim) * 0.02)
+        self.blocks = nn.Sequential(*[_Block(embed_dim, num_heads, mlp_ratio, qkv_bias, init_values, eps)
+                                      for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)     # in the checkpoint, unused by the reference's wrapper
+
+
+def vit_base_patch14_dinov2(pretrained=False, **kwargs):
+    """ timm ``vit_base_patch14_dinov2.lvd142m`` architecture (timm_encoders.py:245-267); weights come
+    from the checkpoint (there is no network here, ``pretrained`` is ignored) """
+    args = dict(patch_size=14, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, init_values=1e-5)
+    args.update(kwargs)
+    return VisionTransformer(**args)
+
+
+def vit_small_patch14_dinov2(pretrained=False, **kwargs):
+    """ timm ``vit_small_patch14_dinov2.lvd142m`` architecture (timm_encoders.py:221-243) """
+    args = dict(patch_size=14, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True, init_values=1e-5)
+    args.update(kwargs)
+    return VisionTransformer(**args)
+
+
+class ViTEncoder(nn.Module):
+    """ mirror of the reference's ViTEncoder: frozen backbone, class token dropped, ``std := mean`` """
+
+    range_fallbacks = {"gemm_precision": {"f16x3": "fp32"}}
+
+    def __init__(self, vit_backbone, num_blocks=None):
+        if not isinstance(vit_backbone, VisionTransformer):
+            raise TypeError("ViT must be a VisionTransfromer")
+        if num_blocks is not None and not 0 <= num_blocks <= len(vit_backbone.blocks):
+            raise ValueError(f"{num_blocks =} must be in [0, {len(vit_backbone.blocks)}]")
+        super().__init__()
+        self.vit_backbone = vit_backbone
+        self.num_blocks = num_blocks
+        if num_blocks is not None:
+            self.vit_backbone.blocks = self.vit_backbone.blocks[:num_blocks]
+        for p in self.parameters():
+            p.requires_grad = False
+        self.mean = torch.tensor(vit_backbone.default_cfg["mean"]).view(1, 1, 3, 1, 1)
+        self.std = torch.tensor(vit_backbone.default_cfg["mean"]).view(1, 1, 3, 1, 1)      # sic (:54-56)
+        self._derived = Derived()
+        self.gemm_precision = knob("TOCVP_VIT_PRECISION", "f16x3")
+        self.max_images = 256                       # frames per chunk (bounds the (n, 257, 3072) MLP scratch)
+
+    # -- derived weights ---------------------------------------------------------------------------
+    def _patch_weights(self):
+        """ patch-embedding GEMM with the normalisation folded in, K padded to a multiple of 64 """
+        proj = self.vit_backbone.patch_embed.proj
+
+        def build():
+            E, C, P, _ = proj.weight.shape
+            mean = self.mean.reshape(1, C, 1, 1).to(proj.weight)
+            std = self.std.reshape(1, C, 1, 1).to(proj.weight)
+            w = (proj.weight / std).reshape(E, C * P * P)
+            b = proj.bias - (proj.weight * (mean / std)).reshape(E, -1).sum(dim=1)
+            kpad = (w.shape[1] + 63) // 64 * 64
+            wp = torch.zeros((E, kpad), device=w.device, dtype=w.dtype)
+            wp[:, :w.shape[1]] = w
+            return wp.contiguous(), b.contiguous()
+        return self._derived.get("patch", [proj.weight, proj.bias], build)
+
+    def _pos_rows(self):
+        """ (cls_token + pos_embed[0]) (1, E) and pos_embed[1:] (N, E) """
+        vb = self.vit_backbone
+        return self._derived.get(
+            "pos", [vb.cls_token, vb.pos_embed],
+            lambda: ((vb.cls_token[0] + vb.pos_embed[0, :1]).contiguous(), vb.pos_embed[0, 1:].contiguous()))
+
+    def _scaled(self, key, lin, ls):
+        """ LayerScale folded into a Linear: (gamma * W, gamma * b) """
+        if not hasattr(ls, "gamma"):
+            return lin.weight, lin.bias
+        return self._derived.get(key, [lin.weight, lin.bias, ls.gamma],
+                                 lambda: ((ls.gamma[:, None] * lin.weight).contiguous(),
+                                          (ls.gamma * lin.bias).contiguous()))
+
+    # -- forward -----------------------------------------------------------------------------------
+    def _forward_chunk(self, imgs):
+        vb = self.vit_backbone
+        n, C, H, W = imgs.shape
+        P, E = vb.patch_size, vb.embed_dim
+        gh, gw = H // P, W // P
+        N = gh * gw
+        wp, bp = self._patch_weights()
+        # im2col = pure data movement: (n, C, gh, P, gw, P) -> (n * N, C * P * P), zero-padded to the GEMM's K
+        cols = torch.zeros((n * N, wp.shape[1]), device=imgs.device, dtype=torch.float32)
+        cols[:, :C * P * P] = imgs.reshape(n, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(n * N, C * P * P)
+        cls_row, pos_rows = self._pos_rows()
+        x = torch.empty((n, N + 1, E), device=imgs.device, dtype=torch.float32)
+        with K.gemm_precision(self.gemm_precision, owner=(self, "gemm_precision")):
+            patches = K.linear(cols, wp, bp, rowvec=pos_rows, rv_div=1)            # + pos_embed[1 + (row % N)]
+            x[:, 0] = cls_row
+            x[:, 1:] = patches.reshape(n, N, E)
+            for i, blk in enumerate(vb.blocks):
+                y = K.layer_norm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+                qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
+                a = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], blk.attn.num_heads,
+                          (E // blk.attn.num_heads) ** -0.5)
+                w, b = self._scaled(("proj", i), blk.attn.proj, blk.ls1)
+                x = K.linear(a, w, b, residual=x)
+                y = K.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+                y = K.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=K.ACT_GELU)
+                w, b = self._scaled(("fc2", i), blk.mlp.fc2, blk.ls2)
+                x = K.linear(y, w, b, residual=x)
+        return x[:, 1:].contiguous()                                               # class token removed (:69)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """ x (n, 3, H, W) or (B, T, 3, H, W) in [0, 1] -> patch features (..., N, E) """
+        lead = x.shape[:-3]
+        imgs = x.reshape(-1, *x.shape[-3:]).contiguous().float()
+        vb = self.vit_backbone
+        if imgs.shape[-1] != vb.img_size or imgs.shape[-2] != vb.img_size:
+            raise ValueError(f"Input image size {tuple(imgs.shape[-2:])} doesn't match model ({vb.img_size})")
+        outs = [self._forward_chunk(imgs[i:i + self.max_images]) for i in range(0, imgs.shape[0], self.max_images)]
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return out.reshape(*lead, *out.shape[1:])
+
+    @torch.no_grad()
+    def _get_num_patches(self):
+        return self.vit_backbone.num_patches

@@ -1,12 +1,13 @@
 """
-ExtendedDINOSAUR video decomposition model, downstream of the ViT backbone, on the MI355X kernels.
+ExtendedDINOSAUR video decomposition model on the MI355X kernels.
 Reference: models/ExtendedDINOSAUR.py (forward_decomp :139-208, decode :211-214).
 
-The DINOv2 ViT backbone is third-party arithmetic (timm, un-pinned, not vendored, pretrained weights
-from the network: SURVEY.md 8c) and is NOT rebuilt.  ``forward_decomp`` therefore takes the backbone's
-patch features through the extension kwarg ``encoded_img_feats`` (B, T, N, mlp_encoder_dim); everything
-after them -- feature projection, slot attention recurrence, transition, MLPPatchDecoder and the CNN
-image head -- runs on the HIP kernels with the reference's parameter names.
+The frozen DINOv2 ViT backbone (models/EncodersDecoders/timm_encoders.py, third-party timm arithmetic:
+parity unpinned, restated from timm's published algorithm) runs on the same GEMM / attention / LayerNorm
+kernels as the predictor.  ``forward_decomp`` batches everything that does not depend on the slots over
+all frames (backbone, feature projection, k/v projection); only the slot recurrence is sequential.
+The extension kwarg ``encoded_img_feats`` (B, T, N, mlp_encoder_dim) bypasses the backbone (features
+computed elsewhere, e.g. cached across predictor experiments).
 """
 
 import math
@@ -20,17 +21,9 @@ from .Blocks.initializers import get_initializer
 from .Blocks.model_utils import RangeGuard, init_xavier_, require_inference
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
+from .EncodersDecoders.encoders import get_encoder
 
 __all__ = ["ExtendedDINOSAUR"]
-
-
-class _BackboneNotVendored(nn.Module):
-    """ stands in for the timm ViT (reference encoders.py:77-95): never holds parameters """
-
-    def forward(self, x):
-        raise NotImplementedError(
-            "the DINOv2 ViT backbone is third-party (timm) and not vendored: pass its patch features "
-            "as encoded_img_feats=(B, T, N, D) to forward_decomp")
 
 
 class ExtendedDINOSAUR(nn.Module, RangeGuard):
@@ -46,9 +39,11 @@ class ExtendedDINOSAUR(nn.Module, RangeGuard):
         if self.img_size is None:
             raise KeyError("'img_size' must be provided in model parameters in order to "
                            "instanciate ViT-based image encoder.")
-        if encoder is not None and "vit" not in encoder["encoder_name"]:
+        if encoder is None or "vit" not in encoder["encoder_name"]:
             raise NameError("Extended-DINOSAUR expects a ViT-Based encoder...")
-        self.encoder = _BackboneNotVendored()
+        encoder = {"encoder_name": encoder["encoder_name"],
+                   "encoder_params": dict(encoder.get("encoder_params", {}), img_size=self.img_size)}
+        self.encoder = get_encoder(in_channels=in_channels, encoder=encoder)
         self.linear_feat_proj = nn.Sequential(
             nn.LayerNorm(mlp_encoder_dim), nn.Linear(mlp_encoder_dim, mlp_encoder_dim), nn.ReLU(),
             nn.Linear(mlp_encoder_dim, slot_dim))
@@ -77,7 +72,8 @@ class ExtendedDINOSAUR(nn.Module, RangeGuard):
         """
         require_inference(self)
         if encoded_img_feats is None:
-            self.encoder(x)                                       # raises: backbone not vendored
+            dev = self.slot_attention.to_q.weight.device
+            encoded_img_feats = self.encoder(x[:, :num_imgs].to(dev))      # (B, T, N, Dm), all frames batched
         feats = encoded_img_feats[:, :num_imgs]
         B, T, N, Dm = feats.shape
         predicted = self.initializer(batch_size=B, **kwargs)

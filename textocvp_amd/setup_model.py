@@ -135,9 +135,6 @@ def load_checkpoint(checkpoint_path, model, only_model=True, map_cpu=False, **kw
     first_ckpt = next(iter(sd.keys()))
     if first_model.startswith("predictor") and not first_ckpt.startswith("predictor"):
         sd = {f"predictor.{k}": v for k, v in sd.items()}
-    if isinstance(model, ExtendedDINOSAUR):
-        # the frozen timm ViT backbone is not vendored here: its weights are skipped
-        sd = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
     # load_state_dict marks the module "range-unchecked" (RangeGuard): its first forward verifies every
     # fp16-plane operand and fails loudly (or forward_eval re-calibrates) instead of saturating silently
     model.load_state_dict(sd)
