@@ -144,14 +144,24 @@ int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const
  * q:(B,Ks,D) contiguous; k,v:(B,N,D) with row stride ldkv (k and v may be the two halves of one
  * fused (B,N,2D) projection); updates:(B,Ks,D).  attn_out (may be NULL): (B,Ks,N) = attn after
  * "+eps" (SlotAttention.attention_masks side effect, attention.py:101).
- * Ks <= 32, D == 128, N % 64 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes.
- * Two launches: a location-streaming partial kernel (k/v read exactly once, coalesced) and a
- * deterministic cross-chunk reduction + renormalisation.
+ * Ks <= 32, D == 128, N % 32 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes, 16-byte aligned
+ * (ticket words + one 16.5 KB partial record per workgroup).
+ * ONE launch (+ a memset node for the ticket words): k and v are streamed exactly once with coalesced
+ * 16-byte loads, both contractions run on the f16 matrix cores with split fp16 operands (fp32-class,
+ * valid for |q * scale|, |k|, |v| < 255), the last-arriving workgroup of a sample adds the partial
+ * records in a fixed order (deterministic) and renormalises.
  * ------------------------------------------------------------------------------------------- */
 size_t tocvp_slot_attn_ws_bytes(int B, int N);
 int tocvp_slot_attn_iter_f32(const float* q, const float* k, const float* v, int ldkv,
                              float* updates, float* attn_out, int B, int Ks, int N, int D,
                              float scale, float eps, void* ws, size_t ws_bytes, void* stream);
+/* Same iteration with k / v already in fp16 operand planes, as the fused [to_k; to_v] projection writes them
+ * through tocvp_gemm_bf16wfrag_f32(c_split = 1, f16x3): kv_planes (B, N, 2 planes, 2 D) fp16 of 2^8 * value,
+ * i.e. one 1 KiB row [k hi | v hi | k lo | v lo] per location.  Same HBM bytes as fp32 k / v, no operand
+ * conversion inside the streaming loop (HBM-bound instead of issue-bound). */
+int tocvp_slot_attn_iter_planes_f32(const float* q, const void* kv_planes, float* updates, float* attn_out,
+                                    int B, int Ks, int N, int D, float scale, float eps, void* ws,
+                                    size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nn.GRUCell gate math (attention.py:105-108), gate order (r,z,n):

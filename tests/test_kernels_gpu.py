@@ -133,6 +133,18 @@ def test_slot_attn_iter(B, Ks, N):
     got = k.slot_attn_iter(q.to(DEV), d[..., :D], d[..., D:], scale, eps, attn_out=attn_out)
     close(got, ref)
     close(attn_out, attn, tol=1e-5)
+    # same iteration fed with the fp16 operand planes the fused kv projection writes (2^8 x = hi + lo)
+    X = kv * 256.0
+    hi = X.half()
+    lo = (X - hi.float()).half()
+    planes = torch.stack([hi, lo], dim=2).contiguous().to(DEV)            # (B, N, 2, 2 D)
+    attn_p = torch.empty((B, Ks, N), device=DEV)
+    got_p = k.slot_attn_iter_planes(q.to(DEV), planes, scale, eps, attn_out=attn_p)
+    close(got_p, ref)
+    close(attn_p, attn, tol=1e-5)
+    # deterministic: the cross-workgroup reduction runs in record order whoever arrives last
+    again = k.slot_attn_iter_planes(q.to(DEV), planes, scale, eps)
+    assert torch.equal(again, got_p)
 
 
 def test_gru_gates():

@@ -72,6 +72,10 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
         ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_slot_attn_iter_planes_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]),
     "tocvp_gru_gates_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -612,6 +616,27 @@ def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
                                        _ptr(attn_out), B, Ks, N, D, float(scale), float(eps),
                                        _ptr(ws), ws.numel() * 4, _stream()),
         "tocvp_slot_attn_iter_f32"))
+    return upd
+
+
+def slot_attn_iter_planes(q, kv_planes, scale, eps, attn_out=None, ws=None):
+    """
+    q (B, Ks, D) fp32; kv_planes (B, N, 2, 2 D) fp16 operand planes of the fused [k | v] projection
+    (linear(..., out_split=22)) -> updates (B, Ks, D).
+    """
+    B, Ks, D = q.shape
+    N = kv_planes.shape[1]
+    _dev_f32(q, "q")
+    assert q.is_contiguous() and kv_planes.is_contiguous() and kv_planes.dtype == torch.float16
+    assert tuple(kv_planes.shape) == (B, N, 2, 2 * D), (kv_planes.shape, (B, N, 2, 2 * D))
+    need = lib().tocvp_slot_attn_ws_bytes(B, N)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, device=q.device, dtype=torch.float32)
+    upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
+    _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
+        lib().tocvp_slot_attn_iter_planes_f32(_ptr(q), _ptr(kv_planes), _ptr(upd), _ptr(attn_out), B, Ks, N, D,
+                                              float(scale), float(eps), _ptr(ws), ws.numel() * 4, _stream()),
+        "tocvp_slot_attn_iter_planes_f32"))
     return upd
 
 

@@ -51,6 +51,9 @@ def _mlp(x, seq, residual):
     return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
 
 
+SD_PLANES = 128          # slot dim of the plane-input slot-attention kernel
+
+
 class SlotAttention(nn.Module):
     """
     Iterative slot attention (reference attention.py:12-128; algorithm :86-110).
@@ -89,21 +92,39 @@ class SlotAttention(nn.Module):
         self.attention_masks = None
         self._derived = Derived()
         self._ws = None
+        self.kv_planes = os.environ.get("TOCVP_SA_KV_PLANES", "1") != "0"    # k / v as fp16 operand planes
 
     # -- k/v projection (once per frame; batched over frames by SAVi) --------------------------
     def project_kv(self, inputs):
-        """ inputs (..., N, Df) -> fused kv (..., N, 2*D): k = [..., :D], v = [..., D:] """
+        """
+        inputs (..., N, Df) -> fused kv: k = [..., :D], v = [..., D:].
+        Under the f16x3 GEMM arithmetic the projection writes fp16 OPERAND PLANES (a kernels.SplitAct of
+        shape (..., N, 2 D): planes (rows, 2, 2 D) of 2^8 * value) that the slot-attention kernel streams
+        without converting anything (same HBM bytes as fp32); otherwise an fp32 tensor (..., N, 2 D).
+        """
         w = self._derived.get("w_kv", [self.to_k.weight, self.to_v.weight],
                               lambda: torch.cat([self.to_k.weight, self.to_v.weight], 0).contiguous())
         b = self._derived.get("b_kv", [self.to_k.bias, self.to_v.bias],
                               lambda: torch.cat([self.to_k.bias, self.to_v.bias], 0).contiguous())
-        return K.linear(_ln(inputs, self.norm_input), w, b)
+        planes = K.active_nsplit() == 22 and self.kv_planes and w.shape[0] == 2 * SD_PLANES
+        return K.linear(_ln(inputs, self.norm_input), w, b, out_split=22 if planes else 0)
+
+    @staticmethod
+    def frame_kv(kv, t, T):
+        """ frame ``t`` of a time-major projection of T frames: (B, N, 2 D) fp32 or (B, N, 2, 2 D) fp16 planes """
+        if isinstance(kv, K.SplitAct):
+            Tn, B, N, D2 = kv.shape
+            assert Tn == T
+            return kv.planes.view(T, B, N, 2, D2)[t]
+        return kv[t]
 
     # -- recurrent refinement ------------------------------------------------------------------
     def iterate(self, kv, slots, num_iters):
-        """ kv (B, N, 2D) from project_kv, slots (B, K, D) -> refined slots (B, K, D) """
+        """ kv from project_kv: (B, N, 2D) fp32 or (B, N, 2, 2D) fp16 planes; slots (B, K, D) -> refined slots """
         B, Ks, D = slots.shape
-        k, v = kv[..., :D], kv[..., D:]
+        if isinstance(kv, K.SplitAct):
+            kv = kv.planes.view(*kv.shape[:-1], 2, kv.shape[-1])
+        planes = kv.dtype == torch.float16
         N = kv.shape[1]
         need = K.lib().tocvp_slot_attn_ws_bytes(B, N)
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != slots.device:
@@ -114,7 +135,11 @@ class SlotAttention(nn.Module):
             q = K.linear(_ln(slots, self.norm_slot), self.to_q.weight, self.to_q.bias)
             if self.store_attention_masks:
                 attn = torch.empty((B, Ks, N), device=slots.device, dtype=torch.float32)
-            upd = K.slot_attn_iter(q, k, v, self.scale, self.epsilon, attn_out=attn, ws=self._ws)
+            if planes:
+                upd = K.slot_attn_iter_planes(q, kv, self.scale, self.epsilon, attn_out=attn, ws=self._ws)
+            else:
+                upd = K.slot_attn_iter(q, kv[..., :D], kv[..., D:], self.scale, self.epsilon, attn_out=attn,
+                                       ws=self._ws)
             gi = K.linear(upd, self.gru.weight_ih, self.gru.bias_ih)
             gh = K.linear(prev, self.gru.weight_hh, self.gru.bias_hh)
             slots = K.gru_gates(gi, gh, prev)

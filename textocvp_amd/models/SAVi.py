@@ -109,10 +109,13 @@ class SAVi(nn.Module, RangeGuard):
         for t0 in range(0, T, chunk):
             t1 = min(T, t0 + chunk)
             kv = self._encode_kv(frames[t0:t1].reshape((t1 - t0) * B, *frames.shape[2:]))
-            kv = kv.reshape(t1 - t0, B, kv.shape[-2], kv.shape[-1])
+            if isinstance(kv, K.SplitAct):                      # fp16 operand planes of the (t1 - t0) * B images
+                kv = K.SplitAct(kv.planes, (t1 - t0, B) + tuple(kv.shape[1:]))
+            else:
+                kv = kv.reshape(t1 - t0, B, kv.shape[-2], kv.shape[-1])
             for t in range(t0, t1):
                 n_it = sa.num_iters_first if t == 0 else sa.num_iters
-                slots = sa.iterate(kv[t - t0], predicted, n_it)
+                slots = sa.iterate(sa.frame_kv(kv, t - t0, t1 - t0), predicted, n_it)
                 predicted = self.transition_module(slots)
                 history.append(slots)
         slot_history = torch.stack(history, dim=1)                      # (B, T, K, D)
