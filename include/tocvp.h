@@ -87,6 +87,19 @@ int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wf
                              const float* rowvec, int rv_div, int rv_mod, int rv_flip,
                              void* C, int c_split, int ldc, int M, int N, int K, int act,
                              void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * f16x3 GEMM on fp16 operand planes of BOTH operands (gemm_f16p.hip): C = act(A W^T + bias) + R.
+ *   A_planes: (M, 2, K) fp16 planes of 2^8 x, as the split epilogues / tocvp_layernorm_split_bf16 write them;
+ *   W_planes: (N, 2, K) fp16 planes of 2^10 w from tocvp_split_weights_planes_f16 (once per weight version);
+ *   C: fp32 (M, N) with row stride ldc, or (c_split) fp16 planes (M, 2, N) for a following planes GEMM.
+ * N % 256 == 0, K % 32 == 0.  Both operands reach LDS by DMA (no conversion, no staging registers),
+ * 256 x 256 or 128 x 256 tiles, 8 waves.  Replaces nn.Linear at Blocks/attention.py:167-175, 355-359.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_split_weights_planes_f16(const float* w, void* out, int N, int K, void* stream);
+int tocvp_gemm_f16planes_f32(const void* A_planes, const void* W_planes, const float* bias, const float* R,
+                             int ldr, void* C, int c_split, int ldc, int M, int N, int K, int act,
+                             void* stream);
+
 /* "f16x3": the same kernel with fp16 planes (x = hi + lo in fp16, 22 significant bits, products
  * hh + hl + lh): fp32-class accuracy at HALF the MFMA count of bf16x6, valid while |x| < 65504. */
 int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* stream);
@@ -249,7 +262,8 @@ int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const
  * matrix cores (three v_mfma_f32_32x32x16_f16 into one fp32 accumulator): ~2^-21 per product, i.e.
  * fp32-class.  Replaces nn.Conv2d(64,64,5,padding=2)+ReLU of ConvDecoder (decoders.py:96-110).
  * Valid for |x| < 255 and |w| < 63 (operands saturate beyond).  in_mode / aux as tocvp_conv5x5_f32,
- * layout as tocvp_conv5x5_f16f8_f32.
+ * layout bits 0 / 1 as tocvp_conv5x5_f16f8_f32; bit 2 selects the persistent form of the kernel (one workgroup
+ * per CU walks its tiles with the next halo staged behind the MFMAs of the current one; same results).
  *   wf: fragment-order weight image written by tocvp_split_conv_weights_dec_f16x3, of
  *   tocvp_conv_weights_dec_f16x3_bytes() bytes.
  * ------------------------------------------------------------------------------------------- */

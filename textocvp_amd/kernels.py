@@ -49,6 +49,11 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_split_weights_planes_f16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_gemm_f16planes_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_layernorm_split_bf16": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
@@ -369,6 +374,8 @@ class gemm_precision:
 
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
+_GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "1") != "0"    # all-DMA planes GEMM for plane inputs with N % 256 == 0
+_GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
 F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
@@ -427,7 +434,8 @@ def active_nsplit():
 
 
 def _split_weight(w, nsplit, frag=False):
-    """ (N, K) fp32 -> cached bf16 planes: (N, nsplit, K) or fragment order (rebuilt on change) """
+    """ (N, K) fp32 -> cached bf16 planes: (N, nsplit, K) or fragment order (rebuilt on change);
+    frag = "rows" with nsplit 22: row-major fp16 planes (N, 2, K) for the all-DMA planes GEMM """
     key = (id(w), nsplit, frag)
     hit = _SPLIT_CACHE.get(key)
     # the weakref guards against id()/address reuse after the original weight was freed
@@ -439,8 +447,12 @@ def _split_weight(w, nsplit, frag=False):
     N, K = w.shape
     if nsplit == 22:
         out = torch.empty((N, 2, K), device=w.device, dtype=torch.float16)
-        _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, K, _stream()),
-               "tocvp_split_weights_frag_f16")
+        if frag == "rows":
+            _check(lib().tocvp_split_weights_planes_f16(_ptr(w), _ptr(out), N, K, _stream()),
+                   "tocvp_split_weights_planes_f16")
+        else:
+            _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, K, _stream()),
+                   "tocvp_split_weights_frag_f16")
         _SPLIT_CACHE[key] = (weakref.ref(w), (w._version, w.data_ptr()), out)
         return out
     out = torch.empty((N, nsplit, K), device=w.device, dtype=torch.bfloat16)
@@ -504,7 +516,15 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         if not pre_split:
             _check_f16_range(float(x2.abs().max()), f"f16x3 GEMM ({M}x{N}x{K}) activation")
         _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
-    if frag_ok:
+    if (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
+            M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
+        # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)
+        ws = _split_weight(w, 22, frag="rows")
+        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+            lib().tocvp_gemm_f16planes_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
+                                           int(bool(out_split)), N, M, N, K, int(act), _stream()),
+            "tocvp_gemm_f16planes_f32"))
+    elif frag_ok:
         ws = _split_weight(w, nsplit, frag=True)
         _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
             lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,
@@ -898,6 +918,12 @@ def split_conv_weights_dec_f16x3(w):
     return wf
 
 
+# persistent form of the decoder conv (one workgroup per CU walking its tiles, next halo staged behind the MFMAs):
+# bit-identical results, measured equal to the two-workgroups-per-CU form (3.90 vs 3.92 ms per 2040 slot images,
+# profiles/r02_conv_f16x3_pmc.md) -> off by default
+_CONV_PERSISTENT = os.environ.get("TOCVP_CONV_PERSISTENT", "0") != "0"
+
+
 def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False):
     """
     64->64 5x5 conv with split-fp16 operands (tocvp_conv5x5_dec_f16x3_f32, fp32-class), fp32 in/out.
@@ -924,7 +950,8 @@ def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=Fa
     def run():
         _check(lib().tocvp_conv5x5_dec_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf), _ptr(bias), _ptr(out),
                                                  n, H, W, Cin, Cout, int(bool(relu)),
-                                                 int(bool(pm_in)) | (int(bool(pm_out)) << 1), _stream()),
+                                                 int(bool(pm_in)) | (int(bool(pm_out)) << 1) |
+                                                 (4 if _CONV_PERSISTENT else 0), _stream()),
                "tocvp_conv5x5_dec_f16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)

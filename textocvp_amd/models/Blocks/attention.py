@@ -19,34 +19,43 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
            "TransformerBlock", "TransformerDecoderBlock", "AdaptedEncoderBlock"]
 
 
-# TOCVP_PRESPLIT=1: activations that only feed GEMMs leave their producer (LayerNorm, attention and GEMM
-# epilogues) as operand planes; with the f16x3 arithmetic (two fp16 planes = the bytes of the fp32 tensor)
-# the large GEMMs then run the DMA-fed 256x128 kernel (gemm_f16_planes_kernel).  Measured in the rollout at
-# B=128: 38400x2048x512 293 vs 301 us, 38400x512x2048 314 vs 301 us, 38400x512x512 118 vs 103 us, total
-# 250 vs 247 ms -> off by default (both forms are bound by L2->CU operand delivery).
+# Activations that only feed GEMMs can leave their producer (LayerNorm, attention and GEMM epilogues) as fp16
+# operand planes (the bytes of the fp32 tensor); a GEMM fed with planes runs the all-DMA planes kernel
+# (gemm_f16p.hip: no split in the k-loop, both operands through LDS).  TOCVP_PRESPLIT:
+#   "0" (default)  never;
+#   "wide"         only where the consuming GEMM is at least 1536 columns wide -- isolated, 38400 rows, f16x3:
+#                  2048x512 311 vs 383 us, 1536x512 223 vs 231 us, but 512x2048 321 vs 281 us and 512x512
+#                  101 vs 77 us (few 256-column tiles: the one-workgroup-per-CU kernel pays its prologue and
+#                  its 256 KB epilogue without cover: ~24 us per workgroup, scripts/gemm_shapes.py);
+#   "1"            everywhere the shapes allow.
+# In the rollout at B=128 (window 1..10, 3840..38400 rows): off 714.3, wide 715.9, all 744.9 ms per step ->
+# neutral at best, so the in-kernel split stays the default.
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0")
+_PRESPLIT_MIN_N = 1536
 
 
 def _ln(x, ln, add=None, split=0):
     return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add, split=split)
 
 
-def _ns(*dims):
+def _ns(*dims, n_out=None):
     """
     planes for split activations under the active GEMM arithmetic (0 = keep fp32 tensors).
-    Activations that only feed GEMMs are emitted by their producer (LayerNorm, GEMM epilogue,
-    attention epilogue) directly as bf16 planes, so each element is split once instead of once
-    per column block of every consuming GEMM.
+    ``dims``: every dimension that must fit the split kernels; ``n_out``: width of the GEMM that consumes
+    the activation (decides in the default "wide" policy).
     """
     ns = K.active_nsplit()
-    if _PRESPLIT == "0":
+    if _PRESPLIT == "0" or not ns:
         return 0
-    return ns if ns and all(d % 64 == 0 for d in dims) else 0
+    if _PRESPLIT == "wide" and (ns != 22 or n_out is None or n_out < _PRESPLIT_MIN_N):
+        return 0
+    return ns if all(d % 64 == 0 for d in dims) else 0
 
 
 def _mlp(x, seq, residual):
     """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
-    ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0])
+    ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0],
+             n_out=seq[2].weight.shape[0])
     h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
     return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
 
@@ -206,7 +215,7 @@ class MultiHeadSelfAttention(MetaAttention):
             lambda: torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous())
         qkv = K.linear(x, w)                                              # (B, T, 3E)
         o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], self.num_heads,
-                  (E // self.num_heads) ** -0.5, out_split=_ns(E))
+                  (E // self.num_heads) ** -0.5, out_split=_ns(E, n_out=self.out_projection[0].weight.shape[0]))
         return K.linear(o, self.out_projection[0].weight, residual=residual)
 
 
@@ -254,7 +263,8 @@ class MultiHeadCrossAttention(MetaAttention):
         inner = self.q.weight.shape[0]
         q = K.linear(query_embs, self.q.weight)
         o = K.mha(q, kv[..., :inner], kv[..., inner:], self.num_heads, self.dim_head ** -0.5,
-                  out_split=_ns(inner, self.out_projection.weight.shape[0]))
+                  out_split=_ns(inner, self.out_projection.weight.shape[0],
+                                n_out=self.out_projection.weight.shape[0]))
         return K.linear(o, self.out_projection.weight, self.out_projection.bias, residual=residual)
 
 
@@ -282,8 +292,9 @@ class TransformerBlock(nn.Module):
         inputs = inputs.contiguous()
         if self.pre_norm:
             E = self.embed_dim
-            y = self.attn(_ln(inputs, self.layernorm_query, split=_ns(E)), residual=inputs)
-            return _mlp(_ln(y, self.layernorm_mlp, split=_ns(E, self.mlp_size)), self.mlp, residual=y)
+            y = self.attn(_ln(inputs, self.layernorm_query, split=_ns(E, n_out=3 * E)), residual=inputs)
+            return _mlp(_ln(y, self.layernorm_mlp, split=_ns(E, self.mlp_size, n_out=self.mlp_size)), self.mlp,
+                        residual=y)
         y = _ln(self.attn(inputs, residual=inputs), self.layernorm_query)
         return _ln(_mlp(y, self.mlp, residual=y), self.layernorm_mlp)
 
@@ -310,10 +321,11 @@ class TransformerDecoderBlock(nn.Module):
         if text_kv is None:
             text_kv = self.project_text(feats)
         E = queries.shape[-1]
-        z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q, split=_ns(E)),
+        z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q,
+                                                 split=_ns(E, n_out=self.cross_attn.q.weight.shape[0])),
                             residual=queries, kv=text_kv)
-        return _mlp(_ln(z, self.ln_mlp, split=_ns(E, self.mlp[0].weight.shape[0])), self.mlp,
-                    residual=z)
+        return _mlp(_ln(z, self.ln_mlp, split=_ns(E, self.mlp[0].weight.shape[0], n_out=self.mlp[0].weight.shape[0])),
+                    self.mlp, residual=z)
 
 
 class AdaptedEncoderBlock(TransformerBlock):
@@ -332,9 +344,10 @@ class AdaptedEncoderBlock(TransformerBlock):
     def forward(self, x, text_embeddings, text_kv=None):
         assert x.ndim == 3, f"Input 'x' must have 3 dims, but got {x.shape = }..."
         E = self.embed_dim
-        y = self.attn(_ln(x, self.layernorm_query, split=_ns(E)), residual=x)
+        y = self.attn(_ln(x, self.layernorm_query, split=_ns(E, n_out=3 * E)), residual=x)
         z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
-        return _mlp(_ln(z, self.layernorm_mlp, split=_ns(E, self.mlp_size)), self.mlp, residual=y)
+        return _mlp(_ln(z, self.layernorm_mlp, split=_ns(E, self.mlp_size, n_out=self.mlp_size)), self.mlp,
+                    residual=y)
 
     def forward_last(self, x, text_embeddings, n_last, text_kv=None):
         """
