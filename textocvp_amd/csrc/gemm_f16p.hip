@@ -16,15 +16,31 @@
 //     conversion instructions); rows are 128 B = [hi k0..31 | lo k0..31]; the image is lane-linear, the
 //     conflict-free order is made on the SOURCE side: physical 16-byte chunk c of row r holds logical chunk
 //     c ^ ((r >> 1) & 7), so the 16 rows of every ds_read_b128 lane group hit 16 distinct slots;
-//   * MI = 4: two LDS stages (2 x 64 KB), one barrier per k-tile (48 MFMAs per wave); MI = 2: THREE stages
-//     (3 x 48 KB) with the DMA two k-tiles ahead, a counted s_waitcnt vmcnt (the newest k-tile stays in
-//     flight across the barrier) and a raw s_barrier (a __syncthreads() would drain the DMA queue);
-//     two waves per SIMD.
+//   * two LDS stages (2 x 64 KB at MI = 4), one barrier per k-tile, two waves per SIMD; the fragments of BOTH
+//     k-steps of a k-tile are in registers before its barrier, so the stage is refilled right behind the barrier
+//     (DMA 1.5 k-tiles ahead with two stages) and every fragment read is issued one MFMA block ahead of its use.
+//
+// Measured (MI355X, 38400 rows, dense random operands, scripts/gemm_shapes.py; round-1 kernel with the in-loop
+// split in brackets): 2048 x 512  311 us = 259 TFLOP/s [383], 2048 x 2048  925 us = 348 [1190], 1536 x 512  227 [231],
+// 512 x 2048  331 [284], 512 x 512  106 [77].  The k-loop runs at ~420 TFLOP/s; a workgroup owns its CU alone and pays
+// ~24 us of prologue + epilogue without cover (its 256 KB of output leave at the ~14 B/clk/CU store-issue rate), so
+// it wins only on wide or deep products.  Ablations (scripts/probes/gemm16p_ablate.hip, 2048 x 512): no DMA -14 %,
+// no stores -12 %, MFMAs removed 0.63 x.  A two-workgroups-per-CU form (256 x 128 tiles, three 16-deep stages, a
+// barrier per 24 MFMAs) measured 389 us on the same product: slower, not kept.  Used for plane inputs when
+// TOCVP_PRESPLIT selects them (off by default: neutral in the rollout, models/Blocks/attention.py).
 #include <stdlib.h>
 
 #include "common.h"
 
+// timing experiments only (scripts/probes/gemm16p_ablate.hip): 1 = no DMA in the k-loop, 2 = no MFMAs,
+// 3 = no LDS fragment reads in the k-loop, 4 = no output stores
+#ifndef TOCVP_GEMM_P2_ABLATE
+#define TOCVP_GEMM_P2_ABLATE 0
+#endif
+
 namespace {
+
+constexpr int PABL = TOCVP_GEMM_P2_ABLATE;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -44,8 +60,9 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-template <int MI, int NSTAGE>
+template <int MI>
 __global__ __launch_bounds__(512, 2) void gemm_f16_planes2_kernel(PArgs p) {
+    constexpr int NSTAGE = 2;
     constexpr int NI = 2, BM = 64 * MI, BN = 256;
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, STAGE = A_STAGE + B_STAGE;
     constexpr int A_DMA = A_STAGE / (8 * 1024), B_DMA = B_STAGE / (8 * 1024);    // 1 KiB instructions per wave
@@ -106,60 +123,62 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_planes2_kernel(PArgs p) {
     // fragment addresses: row = base + l31 (base a multiple of 32), chunk (plane * 4 + ks * 2 + h) ^ ((l31 >> 1) & 7)
     const int x16 = ((l31 >> 1) & 7) << 4;
     const int a_row = (wm * (32 * MI) + l31) * ROWB, b_row = A_STAGE + (wn * 64 + l31) * ROWB;
-    auto compute = [&](int stage) {
+    struct Frags { f16x8 a[MI][2], b[NI][2]; };
+    auto read_frags = [&](Frags& f, int stage, int ks) {
         const unsigned char* sb = lds + stage * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 a[MI][2], b[NI][2];
+        for (int s = 0; s < 2; ++s) {
+            const int coff = (((s * 4 + (PABL == 3 ? 0 : ks) * 2 + h) << 4) ^ x16);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int coff = (((s * 4 + ks * 2 + h) << 4) ^ x16);
+            for (int i = 0; i < MI; ++i) f.a[i][s] = *reinterpret_cast<const f16x8*>(sb + a_row + i * 32 * ROWB + coff);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    a[i][s] = *reinterpret_cast<const f16x8*>(sb + a_row + i * 32 * ROWB + coff);
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    b[j][s] = *reinterpret_cast<const f16x8*>(sb + b_row + j * 32 * ROWB + coff);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < NI; ++j) f.b[j][s] = *reinterpret_cast<const f16x8*>(sb + b_row + j * 32 * ROWB + coff);
         }
     };
+    auto mfma = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if (PABL == 2) {
+                    asm volatile("" :: "v"(f.a[i][0]), "v"(f.a[i][1]), "v"(f.b[j][0]), "v"(f.b[j][1]));
+                    continue;
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
 
-    if (NSTAGE == 2) {
-        dma(0, 0);
-        __syncthreads();                               // with a DMA in flight this also waits vmcnt(0)
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) dma((kt + 1) & 1, kt + 1);
-            compute(kt & 1);
-            __syncthreads();                           // next stage landed, this stage is free
-        }
-    } else {
-        // three stages, DMA two k-tiles ahead.  Per k-tile: wait until only the NEWEST k-tile of this wave's DMA
-        // is still in flight (A_DMA + B_DMA instructions), barrier (every wave's share of k-tile kt has landed and
-        // every wave is done reading the stage of k-tile kt - 1), refill that stage, multiply.  The k-tiles past
-        // the end are clamped re-loads of the last one (never read), so the counted wait stays exact.
-        dma(0, 0);
-        dma(1, nk > 1 ? 1 : 0);
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (A_DMA + B_DMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int fill = st == 0 ? 2 : st - 1;
-            dma(fill, kt + 2 < nk ? kt + 2 : nk - 1);
-            compute(st);
-            st = st == 2 ? 0 : st + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // the epilogue reuses the stages
+    // Software pipeline.  Both k-steps of k-tile kt sit in REGISTERS (f0, f1) before the barrier of iteration kt, so
+    // its stage is refilled right behind that barrier with k-tile kt + 2 (two stages, DMA 1.5 k-tiles ahead of its
+    // use), and the fragment reads of k-tile kt + 1 are issued a whole MFMA block (24 or 48 MFMAs) before their use.
+    Frags f0, f1;
+    // LDS-DMA completion is tracked by vmcnt only: the compiler does not wait for it at a barrier, so every wave
+    // waits for its own share (asm, invisible to the waitcnt pass) and the barrier then covers everybody's.
+    dma(0, 0);
+    dma(1, nk > 1 ? 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_frags(f0, 0, 0);
+    read_frags(f1, 0, 1);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        mfma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of k-tile kt + 1 (issued one iteration ago)
+        __syncthreads();                               // every wave holds k-tile kt in registers; k-tile kt + 1 has landed
+        if (PABL != 1) dma(kt & 1, kt + 2 < nk ? kt + 2 : nk - 1);   // past the end: a harmless re-load, never read
+        read_frags(f0, (kt + 1) & 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(f1, (kt + 1) & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    mfma(f0);
+    mfma(f1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-load of the last k-tile
+    __syncthreads();                                   // the epilogue reuses the stages
 
     // ---- epilogue: 32-row x 64-column blocks staged through LDS, written back as 16-byte rows
     constexpr int SS = 64 + 4;
@@ -184,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_planes2_kernel(PArgs p) {
             if (row < p.M) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + rr * SS + c4);
                 if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                if (PABL == 4 && v[0] != 12345.f) continue;
                 if (p.c_split)
                     tocvp_store_planes4(p.C, (size_t)row * 2 * p.N + col, (size_t)p.N, v, 22);
                 else
@@ -237,10 +257,8 @@ extern "C" int tocvp_gemm_f16planes_f32(const void* A_planes, const void* W_plan
     static const int force = []() { const char* e = getenv("TOCVP_GEMM_P2_MI"); return e ? atoi(e) : 0; }();
     const int mi = force ? force : (big >= 448 ? 4 : 2);
     if (mi == 4)
-        hipLaunchKernelGGL((gemm_f16_planes2_kernel<4, 2>), dim3((unsigned)(((M + 255) / 256) * ntn)), dim3(512), 0, s, p);
-    else if (mi == 2)
-        hipLaunchKernelGGL((gemm_f16_planes2_kernel<2, 3>), dim3((unsigned)(((M + 127) / 128) * ntn)), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(gemm_f16_planes2_kernel<4>, dim3((unsigned)(((M + 255) / 256) * ntn)), dim3(512), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_f16_planes2_kernel<2, 2>), dim3((unsigned)(((M + 127) / 128) * ntn)), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(gemm_f16_planes2_kernel<2>, dim3((unsigned)(((M + 127) / 128) * ntn)), dim3(512), 0, s, p);
     return tocvp_launch_status();
 }
