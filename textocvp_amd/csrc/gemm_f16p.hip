@@ -26,7 +26,8 @@
 // ~24 us of prologue + epilogue without cover (its 256 KB of output leave at the ~14 B/clk/CU store-issue rate), so
 // it wins only on wide or deep products.  Ablations (scripts/probes/gemm16p_ablate.hip, 2048 x 512): no DMA -14 %,
 // no stores -12 %, MFMAs removed 0.63 x.  A two-workgroups-per-CU form (256 x 128 tiles, three 16-deep stages, a
-// barrier per 24 MFMAs) measured 389 us on the same product: slower, not kept.  Used for plane inputs when
+// barrier per 24 MFMAs) measured 389 us on the same product, with or without a start offset that de-phases the two
+// workgroups of a CU: slower, not kept.  Used for plane inputs when
 // TOCVP_PRESPLIT selects them (off by default: neutral in the rollout, models/Blocks/attention.py).
 #include <stdlib.h>
 
