@@ -378,6 +378,16 @@ int tocvp_psnr_ssim_f32(const float* preds, const float* targets, float* psnr, f
 int tocvp_bmm_f32(const float* A, int lda, long sA1, long sA2, int transA, const float* B, int ldb,
                   long sB1, long sB2, int transB, float* C, int ldc, long sC1, long sC2, int nb1,
                   int nb2, int M, int N, int K, float alpha, int accumulate, void* stream);
+/* Weight gradient of nn.Linear without transposes: split z of `splits` reduces token rows
+ * [z * chunk, (z + 1) * chunk) (chunk = ceil(M / splits) rounded up to 16) of
+ *     c_part[z] (N x K) (+)= G[rows]^T X[rows],    bias_part[z] (N) (+)= column sums of G[rows]  (or NULL)
+ * G (M x N, leading dimension ldg) = dL/dY, X (M x K, ldx) = the layer input; exact fp32 MFMA, operands read
+ * as they lie (LDS-DMA).  M % 16 == 0, N % 128 == 0, K % 128 == 0, 16-byte aligned rows.  The caller sums
+ * the splits (fixed order; tocvp_colsum_partial_f32) once per backward pass: every rollout step accumulates
+ * into the same partial buffers.  Replaces autograd's dW = dY^T X / db = sum(dY) of nn.Linear
+ * (04_train_predictor.py:96-104). */
+int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c_part, float* bias_part,
+                      int M, int N, int K, int splits, int accumulate, void* stream);
 /* y[r,:] = softmax(scale * x[r,:]) over the first key_len[r / rows_per_batch] (or all) columns, masked
  * columns 0 (recomputed probabilities of attention backward); ds = scale * p * (dp - <p, dp>). */
 int tocvp_softmax_rows_f32(const float* x, float* y, int rows, int cols, float scale,

@@ -28,6 +28,45 @@ def _ag():
     return autograd
 
 
+@pytest.mark.parametrize("rows", [112, 1600])
+def test_linear_backward_transpose_free_weight_gradient(rows):
+    """ N, K multiples of 128 and M % 16 == 0: dW and db come from tocvp_gemm_tn_f32 (split-K partial sums
+    kept per weight, every use of the weight inside one backward pass accumulates into them; the splits
+    are added once when the tape finishes).  Two uses with different row counts, then a second pass. """
+    ag = _ag()
+    from textocvp_amd import kernels as K
+    assert ag._TN
+    N, Kd = 256, 384
+    w, b = rnd("tw", (N, Kd), "uniform", Kd ** -0.5), rnd("tb", (N,), "uniform", 0.1)
+    xs = [rnd("tx0", (3, rows, Kd)), rnd("tx1", (1, 48, 2, Kd))]
+    gs = [rnd("tg0", (3, rows, N)) * 1e-4, rnd("tg1", (1, 48, 2, N)) * 1e-4]
+    wr, br = w.double().requires_grad_(), b.double().requires_grad_()
+    xrs = [x.double().requires_grad_() for x in xs]
+    for xr, g in zip(xrs, gs):                         # no activation: a ReLU whose pre-activation is within
+        (xr @ wr.t() + br).backward(g.double())        # rounding of 0 would flip against the fp64 reference
+    W, B = ag.Var(w.to(DEV), True), ag.Var(b.to(DEV), True)
+    for rep in (1, 2):
+        tape = ag.Tape()
+        Xs = [ag.Var(x.to(DEV), True) for x in xs]
+        Ys = [ag.linear(tape, X, W, B) for X in Xs]
+        for Y, g in zip(Ys, gs):
+            Y.grad = g.to(DEV)
+        tape.backward()
+        assert rel_err(W.grad, rep * wr.grad) < 1e-5 and rel_err(B.grad, rep * br.grad) < 1e-5
+        for X, xr in zip(Xs, xrs):
+            assert rel_err(X.grad, xr.grad) < 1e-5
+    # deterministic: the same tape twice gives the same bits
+    outs = []
+    for _ in range(2):
+        W2, B2 = ag.Var(w.to(DEV), True), ag.Var(b.to(DEV), True)
+        tape = ag.Tape()
+        Y = ag.linear(tape, ag.Var(xs[0].to(DEV), True), W2, B2)
+        Y.grad = gs[0].to(DEV)
+        tape.backward()
+        outs.append((W2.grad.clone(), B2.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("rows", [100, 512, 4096])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
 def test_linear_backward(act, rows):

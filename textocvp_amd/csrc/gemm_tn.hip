@@ -1,0 +1,143 @@
+// Weight gradient of nn.Linear in the predictor training step (reference
+// 04_train_predictor.py:96-104 lets torch.autograd do this): the "TN" product
+//
+//     dW (N x K) = G^T X        G (M x N) = dL/dY, X (M x K) = the layer input, both row-major fp32,
+//     db (N)     = column sums of G                                             (fused, optional)
+//
+// reduced over the M token rows.  Both operands are read the way they lie in memory (the reduction index is
+// the ROW index of both), so nothing is transposed or re-split on the way: the exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, A[i][k] / B[k][j] one float per lane) takes lane-consecutive floats of one row,
+// which is a conflict-free ds_read_b32 on the natural row-major tile.
+//
+//   * 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 16 token rows per stage, 4 stages of
+//     16 KiB filled by LDS-DMA (global_load_lds, 16 B per lane) three stages ahead of their use; one barrier
+//     per stage.  Rows are stored in PAIRS: [32-column block][row parity][32 floats], so the two k-slices of
+//     an MFMA operand (rows 2s and 2s+1, 32 columns) are 64 consecutive floats = one read per lane, all
+//     64 banks.  The DMA does that interleave on the source side (the LDS side of a DMA is lane-linear).
+//   * split-K over blockIdx.z: split z owns token rows [z * chunk, (z + 1) * chunk) and its own (N x K)
+//     slice of `c_part` (+ (N) of `bias_part`), written or accumulated in place -- the caller keeps one
+//     partial buffer per weight for the whole backward pass (all rollout steps add into it) and reduces the
+//     splits once at the end, in a fixed order: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+struct TnArgs {
+    const float* G; const float* X; float* C; float* bias;
+    int ldg, ldx, M, N, K, chunk, accumulate;
+};
+
+constexpr int TN_T = 128, TN_ROWS = 16, TN_STAGES = 4;
+constexpr int TN_OPER = TN_ROWS * TN_T;            // floats per operand tile (8 KiB)
+constexpr int TN_STAGE = 2 * TN_OPER;              // floats per stage
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
+    __shared__ __attribute__((aligned(1024))) float lds[TN_STAGES * TN_STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int k0 = blockIdx.x * TN_T, n0 = blockIdx.y * TN_T, z = blockIdx.z;
+    const int r_lo = min(p.M, z * p.chunk), r_hi = min(p.M, r_lo + p.chunk);
+    const int nit = (r_hi - r_lo) / TN_ROWS;
+
+    // DMA source offsets (floats) of this lane inside a 2-row block: 128-byte segment s = lane >> 3 holds
+    // row parity s & 1, columns (s >> 1) * 32 + (lane & 7) * 4 ..
+    const int seg = lane >> 3;
+    const int d_row = seg & 1, d_col = (seg >> 1) * 32 + (lane & 7) * 4;
+    const size_t goff = (size_t)d_row * p.ldg + n0 + d_col, xoff = (size_t)d_row * p.ldx + k0 + d_col;
+    auto dma = [&](int it) {
+        float* st = lds + (it & (TN_STAGES - 1)) * TN_STAGE;
+        const int row = r_lo + it * TN_ROWS + wave * 4;           // this wave: row pairs 2 * wave, 2 * wave + 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* gs = p.G + (size_t)(row + 2 * i) * p.ldg + goff;
+            const float* xs = p.X + (size_t)(row + 2 * i) * p.ldx + xoff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gs,
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 256),
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs,
+                                             (__attribute__((address_space(3))) void*)(st + TN_OPER + (wave * 2 + i) * 256),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool want_bias = p.bias != nullptr && blockIdx.x == 0;        // workgroup-uniform
+    float bsum = 0.f;
+    const int b_off = (t >> 7) * 4 * 256 + ((t & 127) >> 5) * 64 + (t & 31);   // half of the row pairs, one column
+
+    for (int it = 0; it < TN_STAGES - 1 && it < nit; ++it) dma(it);
+    for (int it = 0; it < nit; ++it) {
+        // LDS-DMA completion is tracked by vmcnt only; 4 DMA instructions per wave and stage
+        if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (it + 1 < nit) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();              // stage `it` has landed for every wave; stage it - 1 is no longer read
+        if (it + TN_STAGES - 1 < nit) dma(it + TN_STAGES - 1);
+        const float* gs = lds + (it & (TN_STAGES - 1)) * TN_STAGE;
+        const float* xs = gs + TN_OPER;
+#pragma unroll
+        for (int s = 0; s < TN_ROWS / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = gs[s * 256 + (wy * 2 + i) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = xs[s * 256 + (wx * 2 + j) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bsum += gs[b_off + s * 256] + gs[b_off + s * 256 + 32];
+        }
+    }
+
+    float* C = p.C + (size_t)z * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                float* c = C + (size_t)n * p.K + k;
+                *c = p.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+            }
+    if (want_bias) {
+        __syncthreads();
+        lds[t] = bsum;
+        __syncthreads();
+        if (t < 128) {
+            float* b = p.bias + (size_t)z * p.N + n0 + t;
+            const float v = lds[t] + lds[t + 128];
+            *b = p.accumulate ? *b + v : v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c_part,
+                                 float* bias_part, int M, int N, int K, int splits, int accumulate,
+                                 void* stream) {
+    TOCVP_CHECK_ARG(G && X && c_part);
+    TOCVP_CHECK_ARG(M > 0 && M % TN_ROWS == 0 && N > 0 && N % TN_T == 0 && K > 0 && K % TN_T == 0);
+    TOCVP_CHECK_ARG(ldg >= N && ldx >= K && ldg % 4 == 0 && ldx % 4 == 0);
+    TOCVP_CHECK_ARG(tocvp_aligned16(G) && tocvp_aligned16(X));
+    TOCVP_CHECK_ARG(splits >= 1 && splits <= 65535);
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
+    TnArgs a{G, X, c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
+    const dim3 grid(K / TN_T, N / TN_T, splits);
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return tocvp_launch_status();
+}

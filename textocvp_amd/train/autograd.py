@@ -11,6 +11,8 @@ accumulation is an axpby kernel.  torch provides device memory (empty / clone / 
     tape.backward()                         # walks the closures in reverse
 """
 
+import os
+
 import torch
 
 from .. import kernels as K
@@ -21,6 +23,9 @@ __all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "attention_unfuse
 
 _L = K.lib
 _INDEX_CACHE = {}
+# weight / bias gradients of the large linears on the transpose-free split-K kernel (tocvp_gemm_tn_f32)
+_TN = os.environ.get("TOCVP_TRAIN_TN", "1") != "0"
+_TN_TARGET_WGS = 512          # two workgroups per CU
 
 
 def _s():
@@ -56,6 +61,9 @@ class Tape:
     def backward(self):
         for fn in reversed(self.nodes):
             fn()
+        for key, ent in self.cache.items():
+            if isinstance(key, tuple) and key[0] == "tn":
+                _finish_weight_grad(ent)
         self.nodes = []
         self.cache = {}
 
@@ -106,6 +114,52 @@ def colsum(x2, out=None, acc=False):
     return axpby(res, out, 1.0, 1.0 if acc else 0.0)
 
 
+def _sum_splits(part):
+    """ (splits, n) -> (n,): the splits added in index order by one launch """
+    splits, n = part.shape
+    res = torch.empty((1, n), device=part.device, dtype=torch.float32)
+    K._check(_L().tocvp_colsum_partial_f32(_p(part), _p(res), splits, n, n, splits, _s()),
+             "tocvp_colsum_partial_f32")
+    return res.reshape(n)
+
+
+def _weight_grad_tn(tape, W, b, g, x2):
+    """
+    dW += g^T x2 (and db += column sums of g) on tocvp_gemm_tn_f32.  The split-K partial sums of one weight
+    live in ONE buffer per backward pass (tape.cache): every rollout step accumulates into it and
+    Tape.backward() adds the splits into W.grad / b.grad once at the end.
+    """
+    M, N = g.shape
+    Kd = x2.shape[1]
+    want_b = b is not None and b.requires_grad
+    ent = tape.cache.get(("tn", id(W)))
+    first = ent is None
+    if first:
+        tiles = (N // 128) * (Kd // 128)
+        splits = max(1, min(16, -(-_TN_TARGET_WGS // tiles), M // 64))
+        ent = tape.cache[("tn", id(W))] = {
+            "W": W, "b": b if want_b else None, "splits": splits,
+            "part": torch.empty((splits, N * Kd), device=g.device, dtype=torch.float32),
+            "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
+    K._check(_L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
+                                    ent["splits"], 0 if first else 1, _s()), "tocvp_gemm_tn_f32")
+
+
+def _finish_weight_grad(ent):
+    W, b = ent["W"], ent["b"]
+    dW = _sum_splits(ent["part"]).reshape(W.data.shape)
+    if W.grad is None:
+        W.grad = dW
+    else:
+        axpby(dW, W.grad, 1.0, 1.0)
+    if b is not None:
+        db = _sum_splits(ent["bias"])
+        if b.grad is None:
+            b.grad = db
+        else:
+            axpby(db, b.grad, 1.0, 1.0)
+
+
 # ------------------------------------------------------------------------------------------------
 # differentiable ops
 # ------------------------------------------------------------------------------------------------
@@ -137,7 +191,10 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
         # unlike the fp16 planes, with the fp32 exponent range that small gradients need); the operands
         # it wants transposed are copied (data movement).  Everything else takes the generic fp32 kernel.
         fast = M >= 1024 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
-        if W.requires_grad:                               # dW (N, K) = g^T (N, M) x (M, K)
+        tn = _TN and W.requires_grad and M >= 256 and M % 16 == 0 and N % 128 == 0 and Kd % 128 == 0
+        if tn:                                            # dW and db in one transpose-free launch
+            _weight_grad_tn(tape, W, b, g, x2)
+        elif W.requires_grad:                             # dW (N, K) = g^T (N, M) x (M, K)
             splits = min(16, M // 512)
             if fast and M >= 8192 and (N // 64) * (Kd // 64) < 128 and M % splits == 0:
                 # small weight, long reduction: a single GEMM has too few output tiles to fill the chip.
@@ -162,7 +219,7 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
                 bmm(g, x2, W.grad, N, Kd, M, N, Kd, Kd, transA=True)
             else:
                 bmm(g, x2, W.grad, N, Kd, M, N, Kd, Kd, transA=True, acc=True)
-        if b is not None and b.requires_grad:
+        if b is not None and b.requires_grad and not tn:
             if b.grad is None:
                 b.grad = colsum(g)
             else:
