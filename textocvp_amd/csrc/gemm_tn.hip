@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
     const int k0 = blockIdx.x * TN_T, n0 = blockIdx.y * TN_T, z = blockIdx.z;
     const int r_lo = min(p.M, z * p.chunk), r_hi = min(p.M, r_lo + p.chunk);
     const int nit = (r_hi - r_lo) / TN_ROWS;
+    if (nit == 0 && p.accumulate) return;          // nothing to add (workgroup-uniform)
 
     // DMA source offsets (floats) of this lane inside a 2-row block: 128-byte segment s = lane >> 3 holds
     // row parity s & 1, columns (s >> 1) * 32 + (lane & 7) * 4 ..
@@ -62,20 +63,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
         }
     };
 
+    // The accumulators START from the partial sums already in c_part (accumulate) -- the loads are issued
+    // here and land behind the DMA prologue, so the epilogue is stores only.
+    float* C = p.C + (size_t)z * p.N * p.K;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                acc[i][j][r] = p.accumulate ? C[(size_t)n * p.K + k] : 0.f;
+            }
     const bool want_bias = p.bias != nullptr && blockIdx.x == 0;        // workgroup-uniform
     float bsum = 0.f;
     const int b_off = (t >> 7) * 4 * 256 + ((t & 127) >> 5) * 64 + (t & 31);   // half of the row pairs, one column
 
     for (int it = 0; it < TN_STAGES - 1 && it < nit; ++it) dma(it);
     for (int it = 0; it < nit; ++it) {
-        // LDS-DMA completion is tracked by vmcnt only; 4 DMA instructions per wave and stage
+        // LDS-DMA completion is tracked by vmcnt only; 4 DMA instructions per wave and stage (the older
+        // loads of the initial accumulators return in order before them)
         if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (it + 1 < nit) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -101,7 +109,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
         }
     }
 
-    float* C = p.C + (size_t)z * p.N * p.K;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -109,8 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
-                float* c = C + (size_t)n * p.K + k;
-                *c = p.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+                C[(size_t)n * p.K + k] = acc[i][j][r];
             }
     if (want_bias) {
         __syncthreads();
@@ -126,6 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
 
 }  // namespace
 
+// `splits` may be smaller than the number of slices of the caller's buffer when it accumulates (few token
+// rows: fewer, longer reductions); slices >= splits are then left as they are.
 extern "C" int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c_part,
                                  float* bias_part, int M, int N, int K, int splits, int accumulate,
                                  void* stream) {

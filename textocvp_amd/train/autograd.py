@@ -141,8 +141,10 @@ def _weight_grad_tn(tape, W, b, g, x2):
             "W": W, "b": b if want_b else None, "splits": splits,
             "part": torch.empty((splits, N * Kd), device=g.device, dtype=torch.float32),
             "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
+    # later (accumulating) uses with few rows touch only as many slices as they can keep busy
+    active = ent["splits"] if first else max(1, min(ent["splits"], M // 256))
     K._check(_L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
-                                    ent["splits"], 0 if first else 1, _s()), "tocvp_gemm_tn_f32")
+                                    active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32")
 
 
 def _finish_weight_grad(ent):
