@@ -230,7 +230,10 @@ int tocvp_conv5x5_f32(const float* x, const float* aux, int in_mode, const float
 int tocvp_split_conv_weights_bf16(const float* w, void* out, int Cout, int Cin, void* stream);
 /* same weights in MFMA-fragment order (25, 2 passes, 2 k-steps, 2 column blocks, 2 planes, 64 lanes, 8):
  * the kernel then fetches B fragments straight from L1/L2 (no weight image in LDS, no barrier in
- * the tap loop).  Pass either layout (or both; wfrag is preferred). */
+ * the tap loop).  Pass either layout (or both; wfrag is preferred).
+ * relu: 0 none, 1 ReLU, 2 = gate: in_mode 0 with wfrag only, y is zeroed where aux (nimg,H,W,Cout) <= 0 --
+ * the data gradient of the training step's frozen decoder taken through the ReLU of the layer below
+ * (aux = that layer's activation) without a separate masking pass. */
 int tocvp_split_conv_weights_frag_bf16(const float* w, void* out, int Cout, int Cin, void* stream);
 int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in_mode, const void* wsplit,
                              const void* wfrag, const float* bias, float* y, int nimg, int H, int W,
@@ -406,10 +409,12 @@ int tocvp_axpby_f32(const float* x, float* y, long n, float a, float b, void* st
  * more on `partial` with one chunk for the total) */
 int tocvp_colsum_partial_f32(const float* x, float* partial, int rows, int cols, int ld,
                              int rows_per_chunk, void* stream);
-/* nn.LayerNorm backward: dx (rows, D) and per-wave partial sums pgamma / pbeta (nwaves, D), nwaves % 4 == 0 */
+/* nn.LayerNorm backward: dx (rows, D) and per-wave partial sums pgamma / pbeta (nwaves, D), nwaves % 4 == 0,
+ * written, or added to what the rows already hold (accumulate: one partial buffer per parameter collects
+ * every use inside a backward pass and is column-summed once) */
 int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx,
                             float* pgamma, float* pbeta, int nwaves, int rows, int D, float eps,
-                            void* stream);
+                            int accumulate, void* stream);
 /* dW[ids[i], :] += dy[i, :]  (nn.Embedding backward; ids < 0 skipped) */
 int tocvp_embedding_bwd_f32(const int64_t* ids, const float* dy, float* dW, int n, int D, void* stream);
 /* nn.MSELoss: partial[b] = block sums of (pred - target)^2 (nblocks of them), dpred = gscale * (pred - target)

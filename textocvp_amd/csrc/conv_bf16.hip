@@ -257,7 +257,7 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[m][n][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
                     stage[(m * 32 + acc_row(r, h)) * SS + n * 32 + l31] = v;
                 }
         }
@@ -267,8 +267,14 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
         for (int it = 0; it < 16; ++it) {
             const int idx = lane + 64 * it;
             const int px = idx >> 4, c4 = (idx & 15) * 4;          // pixel 0..63 of the wave, channel
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
-            *reinterpret_cast<f32x4*>(ybase + ((size_t)(px >> 5) * p.W + (px & 31)) * C + c4) = v;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
+            const size_t off = ((size_t)(px >> 5) * p.W + (px & 31)) * C + c4;
+            if (MODE == 0 && p.relu == 2) {        // data gradient: gate by the ReLU of the layer below
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.aux + (ybase - p.y) + off);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = g[u] > 0.f ? v[u] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(ybase + off) = v;
         }
     } else {
 #pragma unroll
@@ -281,7 +287,7 @@ void conv5x5_bf16x3_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[m][n][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
                     yrow[(size_t)acc_row(r, h) * C] = v;
                 }
             }
@@ -347,6 +353,7 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
                                         void* stream) {
     TOCVP_CHECK_ARG(x && (wsplit || wfrag) && bias && y);
     TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
+    TOCVP_CHECK_ARG(relu >= 0 && relu <= 2 && (relu != 2 || (in_mode == 0 && aux != nullptr && wfrag != nullptr)));
     TOCVP_CHECK_ARG(Cin == C && Cout == C);
     TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0 && (W % TW) == 0);
     TOCVP_CHECK_ARG((size_t)nimg * (H / TH) * (W / TW) < 0x7fffffffu);
@@ -375,7 +382,7 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
         else                                                                                      \
             hipLaunchKernelGGL((conv5x5_bf16x3_kernel<1, NW_, CCH_>), grid, dim3(NW_ * 64), 0, s, a); \
     } while (0)
-    if (wfrag && (variant == 432 || !wsplit)) {      // weights-direct variant (default when given)
+    if (wfrag && (variant == 432 || !wsplit || relu == 2)) {      // weights-direct variant (default when given)
         if (in_mode == 0)
             hipLaunchKernelGGL((conv5x5_bf16x3_kernel<0, 4, 32, true>), grid, dim3(256), 0, s, a);
         else

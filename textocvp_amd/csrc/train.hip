@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ pgamma, float* __restrict__ pbeta,
-                                                            int rows, int D, float eps) {
+                                                            int rows, int D, float eps, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     f32x4 ag[4], ab[4], gm[4];
@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < 4; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
-            *reinterpret_cast<f32x4*>(pgamma + (size_t)wid * D + c) = ag[i];
-            *reinterpret_cast<f32x4*>(pbeta + (size_t)wid * D + c) = ab[i];
+            f32x4* pg = reinterpret_cast<f32x4*>(pgamma + (size_t)wid * D + c);
+            f32x4* pb = reinterpret_cast<f32x4*>(pbeta + (size_t)wid * D + c);
+            *pg = accumulate ? *pg + ag[i] : ag[i];
+            *pb = accumulate ? *pb + ab[i] : ab[i];
         }
     }
 }
@@ -406,14 +408,14 @@ extern "C" int tocvp_colsum_partial_f32(const float* x, float* partial, int rows
 
 extern "C" int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx,
                                        float* pgamma, float* pbeta, int nwaves, int rows, int D, float eps,
-                                       void* stream) {
+                                       int accumulate, void* stream) {
     TOCVP_CHECK_ARG(x && gamma && dy && dx && pgamma && pbeta);
     TOCVP_CHECK_ARG(rows > 0 && D > 0 && D <= 1024 && (D & 3) == 0 && nwaves > 0 && (nwaves & 3) == 0);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(dy) || !tocvp_aligned16(dx) || !tocvp_aligned16(gamma) ||
         !tocvp_aligned16(pgamma) || !tocvp_aligned16(pbeta))
         return TOCVP_EALIGN;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nwaves / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       gamma, dy, dx, pgamma, pbeta, rows, D, eps);
+                       gamma, dy, dx, pgamma, pbeta, rows, D, eps, accumulate ? 1 : 0);
     return tocvp_launch_status();
 }
 

@@ -155,7 +155,7 @@ _SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_layernorm_bwd_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_embedding_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),
     "tocvp_mse_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -829,10 +829,12 @@ def split_conv_weights_frag_bf16(w):
 _CONV_WD = os.environ.get("TOCVP_CONV_WD", "1") != "0"
 
 
-def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=None):
+def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=None, gate=None):
     """
     64->64 5x5 conv with split-bf16 (bf16x3) operands, fp32 NHWC in/out.
     collapsed=(cpos, S): layer-1 mode fed by the analytically collapsed decoder layer 0.
+    gate (n, H, W, Cout): the output is zeroed where gate <= 0 (data gradient through the ReLU of the layer
+    below, fused into the store); needs wfrag, excludes relu / collapsed.
     """
     if collapsed is not None:
         cpos, S = collapsed
@@ -846,15 +848,20 @@ def conv5x5_bf16x3(x, wsplit, bias, relu=True, out=None, collapsed=None, wfrag=N
         xin, aux, mode, dev = x, None, 0, x.device
     Cout = wsplit.shape[1]
     assert wsplit.dtype == torch.bfloat16 and wsplit.shape == (25, Cout, 2 * Cin)
-    if not _CONV_WD:
+    if not _CONV_WD and gate is None:
         wfrag = None
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
+    code = int(bool(relu))
+    if gate is not None:
+        assert collapsed is None and not relu and wfrag is not None
+        assert gate.is_contiguous() and gate.shape == out.shape and gate.dtype == torch.float32
+        aux, code = gate, 2
 
     def run():
         _check(lib().tocvp_conv5x5_bf16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wsplit), _ptr(wfrag),
                                               _ptr(bias), _ptr(out), n, H, W, Cin, Cout,
-                                              int(bool(relu)), _stream()), "tocvp_conv5x5_bf16x3_f32")
+                                              code, _stream()), "tocvp_conv5x5_bf16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)
     else:

@@ -64,6 +64,11 @@ class Tape:
         for key, ent in self.cache.items():
             if isinstance(key, tuple) and key[0] == "tn":
                 _finish_weight_grad(ent)
+            elif isinstance(key, tuple) and key[0] == "ln":
+                if ent["gamma"].requires_grad:
+                    accumulate(ent["gamma"], colsum(ent["pg"]))
+                if ent["beta"].requires_grad:
+                    accumulate(ent["beta"], colsum(ent["pb"]))
         self.nodes = []
         self.cache = {}
 
@@ -231,6 +236,10 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
                 Wt = tape.cache.get(id(W))          # the same weight is used by every rollout step
                 if Wt is None:
                     Wt = tape.cache[id(W)] = W.data.t().contiguous()
+                if x.grad is not None and x.grad.is_contiguous():      # add into the existing gradient in the epilogue
+                    xg = x.grad.reshape(M, Kd)
+                    K.linear(g, Wt, residual=xg, out=xg, precision="bf16x6")
+                    return
                 dx = K.linear(g, Wt, precision="bf16x6")
             else:
                 dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
@@ -270,14 +279,17 @@ def layer_norm(tape, x, gamma, beta, eps):
         nwaves = min(1024, (rows + 3) // 4 * 4)
         nwaves = max(4, nwaves // 4 * 4)
         dx = torch.empty_like(x.data)
-        pg = torch.empty((nwaves, D), device=dx.device, dtype=torch.float32)
-        pb = torch.empty((nwaves, D), device=dx.device, dtype=torch.float32)
-        K._check(_L().tocvp_layernorm_bwd_f32(_p(x.data), _p(gamma.data), _p(out.grad), _p(dx), _p(pg), _p(pb),
-                                              nwaves, rows, D, float(eps), _s()), "tocvp_layernorm_bwd_f32")
-        if gamma.requires_grad:
-            accumulate(gamma, colsum(pg))
-        if beta.requires_grad:
-            accumulate(beta, colsum(pb))
+        # per-wave partial sums of dgamma / dbeta: one zero-initialised buffer per parameter pair and backward
+        # pass, every use of the LayerNorm adds into it, Tape.backward() column-sums it once
+        ent = tape.cache.get(("ln", id(gamma)))
+        if ent is None:
+            ent = tape.cache[("ln", id(gamma))] = {
+                "gamma": gamma, "beta": beta,
+                "pg": torch.zeros((1024, D), device=dx.device, dtype=torch.float32),
+                "pb": torch.zeros((1024, D), device=dx.device, dtype=torch.float32)}
+        K._check(_L().tocvp_layernorm_bwd_f32(_p(x.data), _p(gamma.data), _p(out.grad), _p(dx), _p(ent["pg"]),
+                                              _p(ent["pb"]), nwaves, rows, D, float(eps), 1, _s()),
+                 "tocvp_layernorm_bwd_f32")
         accumulate(x, dx)
     tape.record(backward)
     return out

@@ -55,9 +55,11 @@ class DecoderLoss:
         return K.conv5x5_bf16x3(x, self.dec._split(i), conv.bias, relu=True, collapsed=collapsed,
                                 wfrag=self.dec._split_frag(i))
 
-    def _conv_bwd(self, i, g):
+    def _conv_bwd(self, i, g, gate=None):
+        """ data gradient of conv block i; ``gate`` = the block's input activation (post-ReLU): the gradient
+        is masked by that ReLU in the store """
         ws, wf = self._backward_weights()[i]
-        return K.conv5x5_bf16x3(g, ws, self._zero_bias, relu=False, wfrag=wf)
+        return K.conv5x5_bf16x3(g, ws, self._zero_bias, relu=False, wfrag=wf, gate=gate)
 
     @torch.no_grad()
     def loss_and_slot_grad(self, slots, targets, grad_scale):
@@ -104,10 +106,7 @@ class DecoderLoss:
             del dy, x3, recons, masks, imgs, dimg
             # conv 3 and 2: data gradient, then the ReLU mask of the layer below
             for i, act in ((3, x2), (2, x1)):
-                graw = self._conv_bwd(i, g)
-                K._check(_L().tocvp_act_bwd_f32(graw.data_ptr(), act.data_ptr(), graw.data_ptr(), graw.numel(),
-                                                K.ACT_RELU, _s()), "tocvp_act_bwd_f32")
-                g = graw
+                g = self._conv_bwd(i, g, gate=act)
             del x1, x2
             gin = self._conv_bwd(1, g)
             dS = torch.empty((n, 25, 64), device=slots.device, dtype=torch.float32)
