@@ -170,16 +170,23 @@ def _finish_weight_grad(ent):
 # ------------------------------------------------------------------------------------------------
 # differentiable ops
 # ------------------------------------------------------------------------------------------------
-def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
-    """ y = act(x W^T + b); x (..., K), W (N, K).  ReLU is fused; GELU keeps the pre-activation. """
+def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None):
+    """
+    y = act(x W^T + b) (+ residual); x (..., K), W (N, K).  ReLU is fused; GELU keeps the pre-activation.
+    residual: a Var of the output's shape added in the GEMM epilogue (no activation then); its gradient is
+    the output gradient itself.
+    """
     N, Kd = W.data.shape
     fused = act if act == K.ACT_RELU else K.ACT_NONE
-    pre = K.linear(x.data, W.data, None if b is None else b.data, act=fused, precision=precision)
+    assert residual is None or act == K.ACT_NONE
+    pre = K.linear(x.data, W.data, None if b is None else b.data, act=fused, precision=precision,
+                   residual=None if residual is None else residual.data)
     y = pre
     if act == K.ACT_GELU:
         y = torch.empty_like(pre)
         K._check(_L().tocvp_act_f32(_p(pre), _p(y), pre.numel(), K.ACT_GELU, _s()), "tocvp_act_f32")
-    out = Var(y, x.requires_grad or W.requires_grad or (b is not None and b.requires_grad))
+    out = Var(y, x.requires_grad or W.requires_grad or (b is not None and b.requires_grad)
+              or (residual is not None and residual.requires_grad))
     if not out.requires_grad:
         return out
 
@@ -236,15 +243,17 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3"):
                 Wt = tape.cache.get(id(W))          # the same weight is used by every rollout step
                 if Wt is None:
                     Wt = tape.cache[id(W)] = W.data.t().contiguous()
-                if x.grad is not None and x.grad.is_contiguous():      # add into the existing gradient in the epilogue
+                if x.grad is not None and x.grad.is_contiguous():      # add into the gradient in the epilogue
                     xg = x.grad.reshape(M, Kd)
                     K.linear(g, Wt, residual=xg, out=xg, precision="bf16x6")
-                    return
-                dx = K.linear(g, Wt, precision="bf16x6")
+                else:
+                    accumulate(x, K.linear(g, Wt, precision="bf16x6"))
             else:
                 dx = torch.empty((M, Kd), device=g.device, dtype=torch.float32)
                 bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
-            accumulate(x, dx)
+                accumulate(x, dx)
+        if residual is not None:                          # last: the residual branch may take over out.grad
+            accumulate(residual, out.grad)
     tape.record(backward)
     return out
 

@@ -76,9 +76,9 @@ class TrainablePredictor:
                     t.add_(0)
 
     # ---------------------------------------------------------------------------------------
-    def _lin(self, tape, x, mod, act=K.ACT_NONE):
+    def _lin(self, tape, x, mod, act=K.ACT_NONE, residual=None):
         return ag.linear(tape, x, self.V(mod.weight), None if mod.bias is None else self.V(mod.bias), act=act,
-                         precision=self.precision)
+                         precision=self.precision, residual=residual)
 
     def _ln(self, tape, x, mod):
         return ag.layer_norm(tape, x, self.V(mod.weight), self.V(mod.bias), mod.eps)
@@ -112,27 +112,28 @@ class TrainablePredictor:
             x = self._ln(tape, ag.add(tape, drop(self._lin(tape, h, layer.linear2)), x), layer.norm2)
         return self._lin(tape, self._ln(tape, x, te.text_out_projection[0]), te.text_out_projection[1])
 
-    def _self_attention(self, tape, x, attn):
+    def _self_attention(self, tape, x, attn, residual=None):
         E = x.data.shape[-1]
         q, k, v = (self._lin(tape, x, m) for m in (attn.q, attn.k, attn.v))
         o = ag.attention(tape, q, k, v, attn.num_heads, (E // attn.num_heads) ** -0.5)
-        return self._lin(tape, o, attn.out_projection[0])
+        return self._lin(tape, o, attn.out_projection[0], residual=residual)
 
-    def _mlp(self, tape, x, seq):
-        return self._lin(tape, self._lin(tape, x, seq[0], act=K.ACT_RELU), seq[2])
+    def _mlp(self, tape, x, seq, residual=None):
+        return self._lin(tape, self._lin(tape, x, seq[0], act=K.ACT_RELU), seq[2], residual=residual)
 
     def _block(self, tape, x, blk, text):
-        """ AdaptedEncoderBlock.forward (attention.py:504-524): note the final residual from y """
-        y = ag.add(tape, self._self_attention(tape, self._ln(tape, x, blk.layernorm_query), blk.attn), x)
+        """ AdaptedEncoderBlock.forward (attention.py:504-524): note the final residual from y.  Every
+        residual sum is the epilogue of the GEMM that produces the other addend. """
+        y = self._self_attention(tape, self._ln(tape, x, blk.layernorm_query), blk.attn, residual=x)
         cb = blk.cross_attention
         ca = cb.cross_attn
         tn = self._ln(tape, text, cb.ln_cross_att_kv)
         q = self._lin(tape, self._ln(tape, y, cb.ln_cross_att_q), ca.q)
         k, v = self._lin(tape, tn, ca.k), self._lin(tape, tn, ca.v)
         o = ag.attention(tape, q, k, v, ca.num_heads, ca.dim_head ** -0.5)      # padded text attends too
-        z1 = ag.add(tape, self._lin(tape, o, ca.out_projection), y)
-        z = ag.add(tape, self._mlp(tape, self._ln(tape, z1, cb.ln_mlp), cb.mlp), z1)
-        return ag.add(tape, self._mlp(tape, self._ln(tape, z, blk.layernorm_mlp), blk.mlp), y)
+        z1 = self._lin(tape, o, ca.out_projection, residual=y)
+        z = self._mlp(tape, self._ln(tape, z1, cb.ln_mlp), cb.mlp, residual=z1)
+        return self._mlp(tape, self._ln(tape, z, blk.layernorm_mlp), blk.mlp, residual=y)
 
     def step(self, tape, window, text):
         """ BaseTextOCVP.forward: window = list of frame Vars (B, K, D) -> next-slot Var (B, K, D) """
