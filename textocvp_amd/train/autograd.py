@@ -37,13 +37,33 @@ def _p(t):
 
 
 class Var:
-    """ a tensor on the tape: ``data`` (contiguous fp32 CUDA), ``grad`` (None until something flows in) """
-    __slots__ = ("data", "grad", "requires_grad", "name")
+    """
+    a tensor on the tape: ``data`` (contiguous fp32 CUDA), ``grad`` (None until something flows in).
+    An op may attach ``recompute`` (a closure that rebuilds ``data`` bit for bit from the op's inputs); the
+    model code can then ``release()`` the activation once its forward consumers have run -- the first
+    backward closure that reads ``data`` rebuilds it, and the producing op drops it again when its own
+    backward has run (it runs after every consumer's).  Activation memory traded for one cheap kernel.
+    """
+    __slots__ = ("_data", "grad", "requires_grad", "name", "recompute")
 
     def __init__(self, data, requires_grad=False, name=None):
         assert data.is_cuda and data.dtype == torch.float32
-        self.data = data if data.is_contiguous() else data.contiguous()
-        self.grad, self.requires_grad, self.name = None, requires_grad, name
+        self._data = data if data.is_contiguous() else data.contiguous()
+        self.grad, self.requires_grad, self.name, self.recompute = None, requires_grad, name, None
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = self.recompute()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
+    def release(self):
+        if self.recompute is not None:
+            self._data = None
 
     @property
     def shape(self):
@@ -189,16 +209,23 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
               or (residual is not None and residual.requires_grad))
     if not out.requires_grad:
         return out
+    if act != K.ACT_GELU:
+        out.recompute = lambda: K.linear(x.data, W.data, None if b is None else b.data, act=fused,
+                                         precision=precision,
+                                         residual=None if residual is None else residual.data)
+        pre = y = None                                   # the ReLU mask is read from out.data
 
     def backward():
         if out.grad is None:
+            out.release()
             return
         g = out.grad.reshape(-1, N)
         if act != K.ACT_NONE:
             gg = torch.empty_like(g)
-            K._check(_L().tocvp_act_bwd_f32(_p(g), _p(pre), _p(gg), g.numel(), int(act), _s()),
-                     "tocvp_act_bwd_f32")
+            K._check(_L().tocvp_act_bwd_f32(_p(g), _p(out.data if pre is None else pre), _p(gg), g.numel(),
+                                            int(act), _s()), "tocvp_act_bwd_f32")
             g = gg
+        out.release()                                     # every consumer's backward has run
         M = g.shape[0]
         x2 = x.data.reshape(M, Kd)
         # Large, aligned shapes run on the split-operand GEMM of the forward pass (bf16x6: fp32-class and,
@@ -275,13 +302,15 @@ def activation(tape, x, act):
 
 
 def layer_norm(tape, x, gamma, beta, eps):
-    y = K.layer_norm(x.data, gamma.data, beta.data, eps)
-    out = Var(y, x.requires_grad or gamma.requires_grad or beta.requires_grad)
+    out = Var(K.layer_norm(x.data, gamma.data, beta.data, eps),
+              x.requires_grad or gamma.requires_grad or beta.requires_grad)
     if not out.requires_grad:
         return out
+    out.recompute = lambda: K.layer_norm(x.data, gamma.data, beta.data, eps)
     D = x.data.shape[-1]
 
     def backward():
+        out.release()                                     # every consumer's backward has run
         if out.grad is None:
             return
         rows = x.data.numel() // D
