@@ -38,6 +38,8 @@ extern "C" {
 #define TOCVP_ACT_NONE 0
 #define TOCVP_ACT_RELU 1
 #define TOCVP_ACT_GELU 2 /* exact erf GELU (nn.TransformerEncoderLayer activation="gelu") */
+#define TOCVP_ACT_GATE 3 /* tocvp_gemm_bf16wfrag_f32 only: y = (R > 0) ? x W^T + b : 0 -- R is read as the gate, not
+                          * added: the data gradient taken through the ReLU whose output is R (training step) */
 
 int tocvp_version(void);
 /* human-readable text for a TOCVP_E* code */

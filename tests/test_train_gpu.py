@@ -67,6 +67,37 @@ def test_linear_backward_transpose_free_weight_gradient(rows):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("single_use", [False, True])
+def test_mlp_backward_with_gated_hidden_gradient(single_use):
+    """ Linear-ReLU-Linear(+residual): with ``single_use`` the hidden gradient leaves the second linear's
+    data-gradient GEMM already masked by the ReLU (TOCVP_ACT_GATE epilogue); same gradients either way.
+    The hidden pre-activations are kept away from 0 so that the fp64 reference takes the same branches. """
+    ag = _ag()
+    from textocvp_amd import kernels as K
+    rows, D, Hd = 1536, 128, 256
+    x = rnd("mx", (rows, D))
+    w1, b1 = rnd("mw1", (Hd, D), "uniform", D ** -0.5), rnd("mb1", (Hd,), "uniform", 0.1)
+    w2, b2 = rnd("mw2", (D, Hd), "uniform", Hd ** -0.5), rnd("mb2", (D,), "uniform", 0.1)
+    pre = x.double() @ w1.double().t() + b1.double()
+    x = x + 0.0
+    close = pre.abs().min(dim=1).values < 1e-4            # rows with a pre-activation near the kink: drop them
+    x = x[~close][:1024].contiguous()
+    gy = rnd("mg", (1024, D))[: x.shape[0]] * 1e-3
+    ref = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    xr, w1r, b1r, w2r, b2r = ref
+    (torch.relu(xr @ w1r.t() + b1r) @ w2r.t() + b2r + xr).backward(gy.double())
+    tape = ag.Tape()
+    X, W1, B1, W2, B2 = (ag.Var(t.to(DEV), True) for t in (x, w1, b1, w2, b2))
+    Hv = ag.linear(tape, X, W1, B1, act=K.ACT_RELU)
+    Hv.single_use = single_use
+    Y = ag.linear(tape, Hv, W2, B2, residual=X)
+    Y.grad = gy.to(DEV)
+    tape.backward()
+    assert Hv.gated == single_use
+    for got, r in zip((X, W1, B1, W2, B2), ref):
+        assert rel_err(got.grad, r.grad) < 1e-5
+
+
 @pytest.mark.parametrize("rows", [100, 512, 4096])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
 def test_linear_backward(act, rows):

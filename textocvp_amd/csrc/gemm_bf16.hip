@@ -38,6 +38,16 @@ struct GemmArgs {
     int c_split;                 // write C as (M, NS, N) bf16 planes instead of fp32
 };
 
+// R operand of the epilogue: residual (added) or, for TOCVP_ACT_GATE, the tensor whose sign gates the output
+__device__ __forceinline__ float with_r(float v, float r, int act) {
+    return act == TOCVP_ACT_GATE ? (r > 0.f ? v : 0.f) : v + r;
+}
+__device__ __forceinline__ f32x4 with_r4(f32x4 v, f32x4 r, int act) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = with_r(v[u], r[u], act);
+    return v;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_split_kernel(GemmArgs
                     v += p.rowvec[(size_t)idx * p.N + col];
                 }
                 v = apply_act(v, p.act);
-                if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                if (p.R) v = with_r(v, p.R[(size_t)row * p.ldr + col], p.act);
                 p.C[(size_t)row * p.ldc + col] = v;
             }
         }
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                 const int row = m0 + wm * WM + i * 32 + rr, col = n0 + wn * WN + c4;
                 if (row < p.M && col < p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
-                    if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                    if (p.R) v = with_r4(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col), p.act);
                     if (p.c_split)      // operand planes for the next split GEMM: (M, NS, N)
                         tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, F16 ? 22 : NS);
                     else
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
                     v += p.rowvec[(size_t)idx * p.N + col];
                 }
                 v = apply_act(v, p.act);
-                if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                if (p.R) v = with_r(v, p.R[(size_t)row * p.ldr + col], p.act);
                 if (p.c_split) {
                     if (F16) v = __builtin_amdgcn_fmed3f(v * E::SA, -65504.f, 65504.f);
                     ET* cs = reinterpret_cast<ET*>(p.C) + (size_t)row * NS * p.N + col;
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_planes_kernel(GemmArgs p) {
             const int row = m0 + wm * 128 + i * 32 + rr, col = n0 + wn * 64 + c4;
             if (row < p.M) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + rr * SS + c4);
-                if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col);
+                if (p.R) v = with_r4(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col), p.act);
                 if (p.c_split)
                     tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, 22);
                 else
@@ -804,7 +814,7 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
     TOCVP_CHECK_ARG(c_split || ldc >= N);
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
-    TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
+    TOCVP_CHECK_ARG((act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU) || (act == TOCVP_ACT_GATE && R != nullptr));
     TOCVP_CHECK_ARG(c_split || ((ldc & 3) == 0 && tocvp_aligned16(C)));
     if ((!a_split && (lda & 3)) || !tocvp_aligned16(A) || !tocvp_aligned16(Wfrag)) return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;

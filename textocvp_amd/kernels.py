@@ -19,6 +19,7 @@ _c_float_p = ctypes.c_void_p
 _LIB = None
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_GATE = 3          # split GEMM epilogue: `residual` is a gate (output zeroed where it is <= 0), see tocvp.h
 
 _SIGNATURES = {
     "tocvp_version": (ctypes.c_int, []),

@@ -44,12 +44,15 @@ class Var:
     backward closure that reads ``data`` rebuilds it, and the producing op drops it again when its own
     backward has run (it runs after every consumer's).  Activation memory traded for one cheap kernel.
     """
-    __slots__ = ("_data", "grad", "requires_grad", "name", "recompute")
+    __slots__ = ("_data", "grad", "requires_grad", "name", "recompute", "single_use", "gated")
 
     def __init__(self, data, requires_grad=False, name=None):
         assert data.is_cuda and data.dtype == torch.float32
         self._data = data if data.is_contiguous() else data.contiguous()
         self.grad, self.requires_grad, self.name, self.recompute = None, requires_grad, name, None
+        # single_use: set by the model code on a ReLU output that feeds exactly one linear -- that linear's
+        # backward may then write the gradient already masked by the ReLU (gated), saving the masking pass
+        self.single_use, self.gated = False, False
 
     @property
     def data(self):
@@ -167,7 +170,7 @@ def _weight_grad_tn(tape, W, b, g, x2):
             "part": torch.empty((splits, N * Kd), device=g.device, dtype=torch.float32),
             "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
     # later (accumulating) uses with few rows touch only as many slices as they can keep busy
-    active = ent["splits"] if first else max(1, min(ent["splits"], M // 256))
+    active = ent["splits"] if first else max(1, min(ent["splits"], M // 128))
     K._check(_L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
                                     active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32")
 
@@ -220,7 +223,7 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
             out.release()
             return
         g = out.grad.reshape(-1, N)
-        if act != K.ACT_NONE:
+        if act != K.ACT_NONE and not (act == K.ACT_RELU and out.gated):
             gg = torch.empty_like(g)
             K._check(_L().tocvp_act_bwd_f32(_p(g), _p(out.data if pre is None else pre), _p(gg), g.numel(),
                                             int(act), _s()), "tocvp_act_bwd_f32")
@@ -273,6 +276,10 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
                 if x.grad is not None and x.grad.is_contiguous():      # add into the gradient in the epilogue
                     xg = x.grad.reshape(M, Kd)
                     K.linear(g, Wt, residual=xg, out=xg, precision="bf16x6")
+                elif x.grad is None and x.single_use and Kd % 32 == 0 and N % 64 == 0:
+                    # x is a ReLU output with no other consumer: the gradient leaves the GEMM already masked
+                    x.grad = K.linear(g, Wt, residual=x2, act=K.ACT_GATE, precision="bf16x6").reshape(x.data.shape)
+                    x.gated = True
                 else:
                     accumulate(x, K.linear(g, Wt, precision="bf16x6"))
             else:

@@ -130,6 +130,7 @@ class TrainablePredictor:
         """ Linear-ReLU-Linear; neither the normalised input nor the hidden activation is kept for the
         backward pass (rebuilt there by one LayerNorm / one GEMM: ``Var.release``) """
         h = self._lin(tape, x, seq[0], act=K.ACT_RELU)
+        h.single_use = True                     # the ReLU mask is applied by the GEMM that produces h.grad
         y = self._lin(tape, h, seq[2], residual=residual)
         if self.recompute_mlp:
             h.release()
