@@ -412,8 +412,9 @@ int tocvp_axpby_f32(const float* x, float* y, long n, float a, float b, void* st
 int tocvp_colsum_partial_f32(const float* x, float* partial, int rows, int cols, int ld,
                              int rows_per_chunk, void* stream);
 /* nn.LayerNorm backward: dx (rows, D) and per-wave partial sums pgamma / pbeta (nwaves, D), nwaves % 4 == 0,
- * written, or added to what the rows already hold (accumulate: one partial buffer per parameter collects
- * every use inside a backward pass and is column-summed once) */
+ * written, or added to what the rows already hold (accumulate bit 0: one partial buffer per parameter
+ * collects every use inside a backward pass and is column-summed once); accumulate bit 1: dx += instead of
+ * dx = (the input already carries the gradient of a residual branch) */
 int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx,
                             float* pgamma, float* pbeta, int nwaves, int rows, int D, float eps,
                             int accumulate, void* stream);

@@ -709,6 +709,15 @@ int launch_wfrag(const GemmArgs& p, hipStream_t s) {
     return tocvp_launch_status();
 }
 
+// 128 x 128 tiles only when there are enough of them: below this count the 64 x 64 kernel fills the CUs better
+static long small_below() {
+    static const long v = []() {
+        const char* e = getenv("TOCVP_GEMM_SMALL_BELOW");
+        return e ? atol(e) : 192L;
+    }();
+    return v;
+}
+
 int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     static const bool planes_kernel = []() {
@@ -721,7 +730,7 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
         hipLaunchKernelGGL(gemm_f16_planes_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
         return tocvp_launch_status();
     }
-    if (big_tiles < 192) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
+    if (big_tiles < small_below()) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
     static const int variant = []() {
         const char* e = getenv("TOCVP_GEMM_VARIANT");
         return e ? atoi(e) : 0;
@@ -738,7 +747,7 @@ int dispatch_wfrag(const GemmArgs& p, hipStream_t s) {
         return e ? atoi(e) : 0;
     }();
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (big_tiles < 192) return launch_wfrag<NS, 64, 64, 32, 32, 4, 1>(p, s);
+    if (big_tiles < small_below()) return launch_wfrag<NS, 64, 64, 32, 32, 4, 1>(p, s);
     if (variant == 1 && big_tiles >= 1024) return launch_wfrag<NS, 256, 128, 64, 64, 8, 2>(p, s);
     if (variant == 2) return launch_wfrag<NS, 128, 128, 64, 32, 8, 2>(p, s);
     return launch_wfrag<NS, 128, 128, 64, 64, 4, 2>(p, s);

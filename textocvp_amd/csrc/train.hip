@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 f32x4 o;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[u] = rstd * (d[i][u] * gm[i][u] - mg - v[i][u] * mgx);
-                *reinterpret_cast<f32x4*>(dx + (size_t)row * D + c) = o;
+                f32x4* dst = reinterpret_cast<f32x4*>(dx + (size_t)row * D + c);
+                *dst = (accumulate & 2) ? *dst + o : o;
             }
         }
     }
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (c < D) {
             f32x4* pg = reinterpret_cast<f32x4*>(pgamma + (size_t)wid * D + c);
             f32x4* pb = reinterpret_cast<f32x4*>(pbeta + (size_t)wid * D + c);
-            *pg = accumulate ? *pg + ag[i] : ag[i];
-            *pb = accumulate ? *pb + ab[i] : ab[i];
+            *pg = (accumulate & 1) ? *pg + ag[i] : ag[i];
+            *pb = (accumulate & 1) ? *pb + ab[i] : ab[i];
         }
     }
 }
@@ -415,7 +416,7 @@ extern "C" int tocvp_layernorm_bwd_f32(const float* x, const float* gamma, const
         !tocvp_aligned16(pgamma) || !tocvp_aligned16(pbeta))
         return TOCVP_EALIGN;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nwaves / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       gamma, dy, dx, pgamma, pbeta, rows, D, eps, accumulate ? 1 : 0);
+                       gamma, dy, dx, pgamma, pbeta, rows, D, eps, accumulate & 3);
     return tocvp_launch_status();
 }
 

@@ -323,7 +323,8 @@ def layer_norm(tape, x, gamma, beta, eps):
         rows = x.data.numel() // D
         nwaves = min(1024, (rows + 3) // 4 * 4)
         nwaves = max(4, nwaves // 4 * 4)
-        dx = torch.empty_like(x.data)
+        into = x.requires_grad and x.grad is not None and x.grad.is_contiguous()     # add into it in the kernel
+        dx = x.grad if into else torch.empty_like(x.data)
         # per-wave partial sums of dgamma / dbeta: one zero-initialised buffer per parameter pair and backward
         # pass, every use of the LayerNorm adds into it, Tape.backward() column-sums it once
         ent = tape.cache.get(("ln", id(gamma)))
@@ -333,9 +334,10 @@ def layer_norm(tape, x, gamma, beta, eps):
                 "pg": torch.zeros((1024, D), device=dx.device, dtype=torch.float32),
                 "pb": torch.zeros((1024, D), device=dx.device, dtype=torch.float32)}
         K._check(_L().tocvp_layernorm_bwd_f32(_p(x.data), _p(gamma.data), _p(out.grad), _p(dx), _p(ent["pg"]),
-                                              _p(ent["pb"]), nwaves, rows, D, float(eps), 1, _s()),
+                                              _p(ent["pb"]), nwaves, rows, D, float(eps), 3 if into else 1, _s()),
                  "tocvp_layernorm_bwd_f32")
-        accumulate(x, dx)
+        if not into:
+            accumulate(x, dx)
     tape.record(backward)
     return out
 
