@@ -18,7 +18,8 @@ import torch
 from .. import kernels as K
 
 __all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "attention_unfused", "dropout", "add",
-           "activation", "add_position_rows", "stack_frames", "take_frame", "embedding", "mask_rows", "mse",
+           "activation", "add_position_rows", "stack_frames", "take_frame", "take_last_tokens", "embedding",
+           "mask_rows", "mse",
            "accumulate", "bmm"]
 
 _L = K.lib
@@ -531,6 +532,21 @@ def take_frame(tape, x, i):
                 return
             g = torch.zeros_like(x.data)
             g[:, i] = out.grad
+            accumulate(x, g)
+        tape.record(backward)
+    return out
+
+
+def take_last_tokens(tape, x, n):
+    """ x (B, T, E) -> its last n tokens (B, n, E) (contiguous copy); the gradient of the other tokens is 0 """
+    B, T, E = x.data.shape
+    out = Var(x.data[:, T - n:].contiguous(), x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is None:
+                return
+            g = torch.zeros((B, T, E), device=out.grad.device, dtype=torch.float32)
+            g[:, T - n:] = out.grad
             accumulate(x, g)
         tape.record(backward)
     return out

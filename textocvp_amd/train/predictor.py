@@ -51,6 +51,7 @@ class TrainablePredictor:
         # drop the LayerNorm outputs and MLP hidden activations after their forward use and rebuild them
         # in the backward pass.  Measured at B=32, K=30, 19 predictions: "0" 63.6 GB, "ln" 55.0 GB at no cost in time,
         # "all" 50.0 GB for +3 % time (every activation is also dropped as soon as its producer has back-propagated)
+        self.last_layer_newest_frame_only = os.environ.get("TOCVP_LAST_LAYER_SUBSET", "1") != "0"
         mode = os.environ.get("TOCVP_TRAIN_RECOMPUTE", "ln")           # "ln" | "mlp" | "all" | "0"
         self.recompute_ln = mode in ("all", "1", "ln")
         self.recompute_mlp = mode in ("all", "1", "mlp")
@@ -138,27 +139,61 @@ class TrainablePredictor:
             x.release()
         return y
 
-    def _block(self, tape, x, blk, text):
-        """ AdaptedEncoderBlock.forward (attention.py:504-524): note the final residual from y.  Every
-        residual sum is the epilogue of the GEMM that produces the other addend. """
-        xq = self._ln(tape, x, blk.layernorm_query)
-        y = self._self_attention(tape, xq, blk.attn, residual=x)
+    def text_kv(self, tape, text):
+        """ per layer: cross-attention keys / values of the caption.  They do not depend on the rollout step,
+        so they are projected ONCE per sequence (as the inference path does, BaseTextOCVP.prepare_text); every
+        step's attention adds into the same k / v gradients and the projections back-propagate once. """
+        out = []
+        for blk in self.pred.predictor:
+            cb = blk.cross_attention
+            tn = self._ln(tape, text, cb.ln_cross_att_kv)
+            out.append((self._lin(tape, tn, cb.cross_attn.k), self._lin(tape, tn, cb.cross_attn.v)))
+        return out
+
+    def _after_self_attention(self, tape, y, blk, kv):
+        """ the row-wise rest of AdaptedEncoderBlock.forward (attention.py:512-524): text cross-attention block,
+        then the MLP whose residual comes from y (the reference's wiring) """
         cb = blk.cross_attention
         ca = cb.cross_attn
-        tn = self._ln(tape, text, cb.ln_cross_att_kv)
         yq = self._ln(tape, y, cb.ln_cross_att_q)
         q = self._lin(tape, yq, ca.q)
         if self.recompute_ln:
-            xq.release()
             yq.release()
-        k, v = self._lin(tape, tn, ca.k), self._lin(tape, tn, ca.v)
-        o = ag.attention(tape, q, k, v, ca.num_heads, ca.dim_head ** -0.5)      # padded text attends too
+        o = ag.attention(tape, q, kv[0], kv[1], ca.num_heads, ca.dim_head ** -0.5)   # padded text attends too
         z1 = self._lin(tape, o, ca.out_projection, residual=y)
         z = self._mlp(tape, self._ln(tape, z1, cb.ln_mlp), cb.mlp, residual=z1)
         return self._mlp(tape, self._ln(tape, z, blk.layernorm_mlp), blk.mlp, residual=y)
 
-    def step(self, tape, window, text):
-        """ BaseTextOCVP.forward: window = list of frame Vars (B, K, D) -> next-slot Var (B, K, D) """
+    def _block(self, tape, x, blk, kv):
+        """ AdaptedEncoderBlock.forward (attention.py:504-524).  Every residual sum is the epilogue of the
+        GEMM that produces the other addend. """
+        xq = self._ln(tape, x, blk.layernorm_query)
+        y = self._self_attention(tape, xq, blk.attn, residual=x)
+        if self.recompute_ln:
+            xq.release()
+        return self._after_self_attention(tape, y, blk, kv)
+
+    def _block_last(self, tape, x, blk, kv, n):
+        """
+        The final layer: only the newest frame's n tokens of its output are read (text_cond_OCVP.py:101-103),
+        and only self-attention mixes tokens -- keys / values over the whole window, everything else on the
+        n rows that are consumed (the inference path's AdaptedEncoderBlock.forward_last).  The dropped rows
+        carry exactly zero gradient in the reference as well.
+        """
+        attn = blk.attn
+        E = x.data.shape[-1]
+        xq = self._ln(tape, x, blk.layernorm_query)
+        k, v = self._lin(tape, xq, attn.k), self._lin(tape, xq, attn.v)
+        q = self._lin(tape, ag.take_last_tokens(tape, xq, n), attn.q)
+        if self.recompute_ln:
+            xq.release()
+        o = ag.attention(tape, q, k, v, attn.num_heads, (E // attn.num_heads) ** -0.5)
+        y = self._lin(tape, o, attn.out_projection[0], residual=ag.take_last_tokens(tape, x, n))
+        return self._after_self_attention(tape, y, blk, kv)
+
+    def step(self, tape, window, text_kv):
+        """ BaseTextOCVP.forward: window = list of frame Vars (B, K, D) -> next-slot Var (B, K, D);
+        text_kv = self.text_kv(tape, text) """
         p = self.pred
         w = len(window)
         slots = ag.stack_frames(tape, window)                                   # (B, w, K, D)
@@ -173,11 +208,13 @@ class TrainablePredictor:
         E = tokens.data.shape[-1]
         x = ag.Var(tokens.data.reshape(B, w * Ks, E), tokens.requires_grad)
         tape.record(lambda xv=x, tv=tokens: ag.accumulate(tv, xv.grad) if xv.grad is not None else None)
-        for blk in p.predictor:
-            x = self._block(tape, x, blk, text)
-        x4 = ag.Var(x.data.reshape(B, w, Ks, E), x.requires_grad)
-        tape.record(lambda xv=x, x4v=x4: ag.accumulate(xv, x4v.grad) if x4v.grad is not None else None)
-        last = ag.take_frame(tape, x4, w - 1)
+        nblk = len(p.predictor)
+        for i, (blk, kv) in enumerate(zip(p.predictor, text_kv)):
+            if i == nblk - 1 and self.last_layer_newest_frame_only:
+                x = self._block_last(tape, x, blk, kv, Ks)                      # (B, K, E)
+            else:
+                x = self._block(tape, x, blk, kv)
+        last = x if nblk and self.last_layer_newest_frame_only else ag.take_last_tokens(tape, x, Ks)
         out = self._lin(tape, last, p.mlp_out)
         return ag.add(tape, out, window[-1]) if p.residual else out
 
@@ -185,12 +222,12 @@ class TrainablePredictor:
         """ PredictorWrapper.forward: returns the list of predicted-slot Vars (B, K, D) """
         wr = self.wrapper
         num_preds = wr.num_preds if num_preds is None else num_preds
-        text = self.encode_text(tape, tokens, lengths)
+        text_kv = self.text_kv(tape, self.encode_text(tape, tokens, lengths))
         window = [ag.Var(slot_history[:, i].contiguous()) for i in range(wr.num_context)]
         preds = []
         teacher = wr.exp_params["prediction_params"]["teacher_force"]
         for t in range(num_preds):
-            cur = self.step(tape, window, text)
+            cur = self.step(tape, window, text_kv)
             nxt = ag.Var(slot_history[:, wr.num_context + t].contiguous()) if teacher else cur
             window = (window + [nxt])[-wr.input_buffer_size:]
             preds.append(cur)
