@@ -21,7 +21,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   "rooflines":    that entry + predictor GEMM, predictor attention and the slot-attention iteration
                   (HBM-bound, GB/s), each timed with HIP events in one extra untimed pass,
   "cpu_baseline": the CPU oracle (oracle/, kind "port") on a bounded sample: warm-up + 5 timed reps,
-  "extra":        the same measurement at the authors' evaluation batch (32 sequences per GPU).
+  "extra":        the same measurement at the authors' evaluation batch (32 sequences per GPU), at 8 and at 1
+                  (the latency of one sequence).
 """
 
 import argparse
@@ -64,7 +65,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TOCVP_BENCH_BATCH", 128)),
                     help="sequences per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the batch-32 line and the per-kernel pass")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batch-32 / 8 / 1 lines and the per-kernel pass")
     return ap.parse_args()
 
 
@@ -267,13 +268,19 @@ def main():
         timer_all, kernels.TIMER = kernels.TIMER, None
 
     extra = None
-    if not args.no_extra and B != 32:
-        el32, _, _ = timed(make_inputs(32), 1, max(2, args.steps))
-        extra = {"batch_32": {"value": round(world * 32 * NUM_PREDS * max(2, args.steps) / el32, 2),
-                              "unit": "predicted frames/s", "batch_per_gpu": 32,
-                              "ms_per_step": round(1e3 * el32 / max(2, args.steps), 2),
-                              "note": "the authors' evaluation batch (scripts/05_evaluate_TextOCVP_CATER.sh); "
-                                      "decoder overlapped with the rollout on a second stream"}}
+    if not args.no_extra:
+        extra = {}
+        notes = {32: "the authors' evaluation batch (scripts/05_evaluate_TextOCVP_CATER.sh)",
+                 8: "small evaluation batch", 1: "one sequence: ms_per_step is the latency of 1 seed + 19 predicted "
+                                                  "frames, encoder to metrics"}
+        for b in (32, 8, 1):
+            if b == B:
+                continue
+            n = max(2, args.steps)
+            el, _, _ = timed(make_inputs(b), 1, n)
+            extra[f"batch_{b}"] = {"value": round(world * b * NUM_PREDS * n / el, 2), "unit": "predicted frames/s",
+                                   "batch_per_gpu": b, "ms_per_step": round(1e3 * el / n, 2),
+                                   "note": notes[b] + "; decoder overlapped with the rollout on a second stream"}
 
     if rank == 0:
         frames = world * B * NUM_PREDS * args.steps
