@@ -393,6 +393,15 @@ int tocvp_bmm_f32(const float* A, int lda, long sA1, long sA2, int transA, const
  * (04_train_predictor.py:96-104). */
 int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c_part, float* bias_part,
                       int M, int N, int K, int splits, int accumulate, void* stream);
+/* Backward of multi-head softmax attention, fused (scores / probabilities never reach HBM), exact fp32 MFMA:
+ * q, o, d_o, dq (B, Tq, E); k, v, dk, dv (B, Tk, E); E = H * 64; o = the forward output; stats (B, H, Tq, 2) is
+ * scratch (log-sum-exp and <dO, O> per query row); key_len (B) int32 or NULL masks keys >= key_len[b] (their
+ * dk / dv rows are zero).  dq / dk / dv are overwritten.  Three launches (row statistics; dK, dV with a wave
+ * per 32 keys; dQ with a wave per 32 queries), no atomics.  Replaces autograd through
+ * MetaAttention.attention (attention.py:157-176) in the training step. */
+int tocvp_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                       float* dq, float* dk, float* dv, float* stats, const int32_t* key_len, int B, int H,
+                       int Tq, int Tk, int E, float scale, void* stream);
 /* y[r,:] = softmax(scale * x[r,:]) over the first key_len[r / rows_per_batch] (or all) columns, masked
  * columns 0 (recomputed probabilities of attention backward); ds = scale * p * (dp - <p, dp>). */
 int tocvp_softmax_rows_f32(const float* x, float* y, int rows, int cols, float scale,

@@ -147,10 +147,13 @@ def test_layer_norm_backward():
     assert rel_err(B.grad, br.grad) < 2e-5
 
 
-@pytest.mark.parametrize("Tq,Tk,lens", [(70, 70, None), (30, 12, [12, 5, 9])])
-def test_attention_backward(Tq, Tk, lens):
+@pytest.mark.parametrize("H,E", [(4, 128), (4, 256)])
+@pytest.mark.parametrize("Tq,Tk,lens", [(70, 70, None), (30, 12, [12, 5, 9]), (300, 300, None), (150, 40, [40, 33, 1])])
+def test_attention_backward(Tq, Tk, lens, H, E):
+    """ head size 32: the batched-GEMM chain (scores materialised); head size 64 (the predictor's): the fused
+    backward of csrc/attn_bwd.hip, ragged tile edges and key padding included """
     ag = _ag()
-    B, H, E = 3, 4, 128
+    B = 3
     q, k, v = rnd("aq", (B, Tq, E)), rnd("ak", (B, Tk, E)), rnd("av", (B, Tk, E))
     go = rnd("ago", (B, Tq, E))
     scale = (E // H) ** -0.5

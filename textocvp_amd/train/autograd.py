@@ -27,6 +27,7 @@ _INDEX_CACHE = {}
 # weight / bias gradients of the large linears on the transpose-free split-K kernel (tocvp_gemm_tn_f32)
 _TN = os.environ.get("TOCVP_TRAIN_TN", "1") != "0"
 _TN_TARGET_WGS = 512          # two workgroups per CU
+_FUSED_ATTN_BWD = os.environ.get("TOCVP_TRAIN_FUSED_ATTN_BWD", "1") != "0"
 
 
 def _s():
@@ -358,6 +359,17 @@ def attention(tape, q, k, v, heads, scale, key_len=None):
             return
         dO = out.grad
         dev = dO.device
+        if _FUSED_ATTN_BWD and dh == 64 and dO.is_contiguous():
+            # one fused backward (csrc/attn_bwd.hip): scores and probabilities stay on the chip
+            stats = torch.empty((B, heads, Tq, 2), device=dev, dtype=torch.float32)
+            dQ, dK, dV = torch.empty_like(q.data), torch.empty_like(k.data), torch.empty_like(v.data)
+            K._check(_L().tocvp_attn_bwd_f32(_p(q.data), _p(k.data), _p(v.data), _p(out.data), _p(dO), _p(dQ),
+                                             _p(dK), _p(dV), _p(stats), _p(key_len), B, heads, Tq, Tk, E,
+                                             float(scale), _s()), "tocvp_attn_bwd_f32")
+            accumulate(q, dQ)
+            accumulate(k, dK)
+            accumulate(v, dV)
+            return
         hb = (B, heads)
         sQ, sK = (Tq * E, dh), (Tk * E, dh)
         sS = (heads * Tq * Tk, Tq * Tk)
