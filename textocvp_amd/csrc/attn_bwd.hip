@@ -61,12 +61,20 @@ __device__ __forceinline__ float tile_row_elem(const float* tile, int l31, int h
 __device__ __forceinline__ float tile_col_elem(const float* tile, int l31, int h, int r, int half) {
     return tile[acc_row(r, h) * LDT + l31 + 32 * half];
 }
-// B-operand registers of a wave's OWN tile: b[s] = X[row0 + l31][2 s + h] straight from global (once per kernel)
-__device__ __forceinline__ void own_rows(float (&b)[32], const float* base, int row0, int T, int E, int l31, int h) {
-    const bool ok = row0 + l31 < T;
-    const float* p = base + (size_t)(row0 + l31) * E + h;
+// B-operand registers of every wave's OWN tile: b[s] = X[row0(wave) + l31][2 s + h].  The workgroup's four
+// tiles (128 consecutive rows) are fetched with coalesced 16-byte loads into four LDS tile slots and read back
+// in operand order (a lane reading every other float of its own row from global costs 32 x 32 cache lines).
+__device__ __forceinline__ void own_rows(float (&b)[32], float* slots, const float* base, int row0_wg, int T, int E,
+                                         int t, int wave, int l31, int h) {
+    TileRegs r[4];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) b[s] = ok ? p[2 * s] : 0.f;
+    for (int w = 0; w < 4; ++w) tile_fetch(r[w], base, row0_wg + w * TS, T, E, t);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) tile_stash(slots + w * TILE, r[w], t);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 32; ++s) b[s] = tile_row_elem(slots + wave * TILE, l31, h, s);
+    __syncthreads();                               // the slots are reused by the caller
 }
 __device__ __forceinline__ void zero(f32x16& a) {
 #pragma unroll
@@ -76,8 +84,8 @@ __device__ __forceinline__ void zero(f32x16& a) {
 // ---------------------------------------------------------------------------------------------
 // stats: grid (B * H, ceil(Tq / 128)); wave w of a workgroup owns queries i0 = (blockIdx.y * 4 + w) * 32 ..
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AbArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+__global__ __launch_bounds__(256, 2) void attn_bwd_stats_kernel(AbArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
     const int kl = p.key_len ? min(p.key_len[b], p.Tk) : p.Tk;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AbArgs p) {
     const int i0 = (blockIdx.y * 4 + wave) * TS;
     const bool active = i0 < p.Tq;                                  // wave-uniform
     float qb[32];
-    own_rows(qb, Q, i0, p.Tq, p.E, l31, h);
+    own_rows(qb, lds, Q, blockIdx.y * 4 * TS, p.Tq, p.E, t, wave, l31, h);
     const float sc2 = p.scale * LOG2E;
     float m_run = -INFINITY, l_run = 0.f;
     const int nj = (kl + TS - 1) / TS;
@@ -110,15 +118,15 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AbArgs p) {
         }
         float add = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) add += m_new == -INFINITY ? 0.f : exp2f(st[r] - m_new);
-        l_run = (m_run == -INFINITY ? 0.f : l_run * exp2f(m_run - m_new)) + add;
+        for (int r = 0; r < 16; ++r) add += m_new == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(st[r] - m_new);
+        l_run = (m_run == -INFINITY ? 0.f : l_run * __builtin_amdgcn_exp2f(m_run - m_new)) + add;
         m_run = m_new;
     }
     if (!active) return;
     // the two lane halves saw disjoint key rows of every tile: merge them
     const float m_o = __shfl_xor(m_run, 32, 64), l_o = __shfl_xor(l_run, 32, 64);
     const float m = fmaxf(m_run, m_o);
-    const float l = (m_run == -INFINITY ? 0.f : l_run * exp2f(m_run - m)) + (m_o == -INFINITY ? 0.f : l_o * exp2f(m_o - m));
+    const float l = (m_run == -INFINITY ? 0.f : l_run * __builtin_amdgcn_exp2f(m_run - m)) + (m_o == -INFINITY ? 0.f : l_o * __builtin_amdgcn_exp2f(m_o - m));
     // delta_i = <dO_i, O_i>: half h sums head columns 32 h .. 32 h + 31 of the lane's query row
     float d = 0.f;
     if (i0 + l31 < p.Tq) {
@@ -141,8 +149,9 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AbArgs p) {
 // ---------------------------------------------------------------------------------------------
 // dkv: grid (B * H, ceil(Tk / 128)); wave w owns keys j0 = (blockIdx.y * 4 + w) * 32 ..
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AbArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AbArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (2 * TILE + 2 * TS)];
+    static_assert(2 * (2 * TILE + 2 * TS) >= 4 * TILE, "four tile slots for own_rows");
     constexpr int STAGE = 2 * TILE + 2 * TS;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AbArgs p) {
     const int j0 = (blockIdx.y * 4 + wave) * TS;
     const bool active = j0 < kl;                                    // wave-uniform; masked keys get zero gradients
     float kb[32], vb[32];
-    own_rows(kb, Kp, j0, p.Tk, p.E, l31, h);
-    own_rows(vb, Vp, j0, p.Tk, p.E, l31, h);
+    own_rows(kb, lds, Kp, blockIdx.y * 4 * TS, p.Tk, p.E, t, wave, l31, h);
+    own_rows(vb, lds, Vp, blockIdx.y * 4 * TS, p.Tk, p.E, t, wave, l31, h);
     f32x16 dk[2], dv[2];
     zero(dk[0]); zero(dk[1]); zero(dv[0]); zero(dv[1]);
     const float sc2 = p.scale * LOG2E;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AbArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, h);
             const bool ok = key_ok && i * TS + row < p.Tq;
-            const float pr = ok ? exp2f(s_acc[r] * sc2 - Ss[2 * row]) : 0.f;
+            const float pr = ok ? __builtin_amdgcn_exp2f(s_acc[r] * sc2 - Ss[2 * row]) : 0.f;
             s_acc[r] = pr;                                                        // P
             p_acc[r] = pr * (p_acc[r] - Ss[2 * row + 1]) * p.scale;               // dS
         }
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AbArgs p) {
 // ---------------------------------------------------------------------------------------------
 // dq: grid (B * H, ceil(Tq / 128)); wave w owns queries i0 = (blockIdx.y * 4 + w) * 32 ..
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AbArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AbArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
@@ -231,8 +240,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AbArgs p) {
     const int i0 = (blockIdx.y * 4 + wave) * TS;
     const bool active = i0 < p.Tq;
     float qb[32], gb[32];
-    own_rows(qb, Q, i0, p.Tq, p.E, l31, h);
-    own_rows(gb, DO, i0, p.Tq, p.E, l31, h);
+    own_rows(qb, lds, Q, blockIdx.y * 4 * TS, p.Tq, p.E, t, wave, l31, h);
+    own_rows(gb, lds, DO, blockIdx.y * 4 * TS, p.Tq, p.E, t, wave, l31, h);
     const bool q_ok = i0 + l31 < p.Tq;
     const float* st = p.stats + ((size_t)blockIdx.x * p.Tq + min(i0 + l31, p.Tq - 1)) * 2;
     const float lse = st[0], delta = st[1];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AbArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool ok = q_ok && j * TS + acc_row(r, h) < kl;
-            const float pr = ok ? exp2f(st_acc[r] * sc2 - lse) : 0.f;
+            const float pr = ok ? __builtin_amdgcn_exp2f(st_acc[r] * sc2 - lse) : 0.f;
             st_acc[r] = pr * (pt_acc[r] - delta) * p.scale;                       // dS^T
         }
 #pragma unroll
