@@ -243,59 +243,67 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restric
     constexpr int F4 = DT_CC / 4;                                   // float4 per pixel per pass
     constexpr int NIT = (DT_IH * DT_IW * F4 + 255) / 256;           // 11 loads per thread per pass
 
-    for (int k = 0; k < K; ++k) {
-        const float* xi = x + ((size_t)f * K + k) * HW * DT_C;
-        f32x4 acc = bv;
+    // One step = (slot image k, 32-channel pass).  The halo tile of step s + 1 is fetched into registers BEFORE the
+    // FMAs of step s (its ~2 us of memory latency then runs under ~1 us of FMAs here plus the partner
+    // workgroup's), instead of in front of its own barrier.
+    f32x4 tv[NIT];
+    auto fetch = [&](int step) {
+        const float* xi = x + ((size_t)f * K + (step >> 1)) * HW * DT_C + (step & 1) * DT_CC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {                          // batched, clamped loads
+            const int i = min(t + it * 256, DT_IH * DT_IW * F4 - 1);
+            const int p = i / F4, c = (i % F4) * 4;
+            const int iy = min(max(ty0 + p / DT_IW - 1, 0), H - 1);
+            const int ix = min(max(tx0 + p % DT_IW - 1, 0), W - 1);
+            tv[it] = *reinterpret_cast<const f32x4*>(xi + ((size_t)iy * W + ix) * DT_C + c);
+        }
+    };
+    fetch(0);
+    f32x4 acc = bv;
 #pragma unroll 1
-        for (int pass = 0; pass < DT_C / DT_CC; ++pass) {
-            f32x4 tv[NIT];
+    for (int step = 0; step < 2 * K; ++step) {
+        const int k = step >> 1, pass = step & 1;
+        __syncthreads();                                            // previous step consumed
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {                      // batched, clamped loads
-                const int i = min(t + it * 256, DT_IH * DT_IW * F4 - 1);
+        for (int it = 0; it < NIT; ++it) {
+            const int i = t + it * 256;
+            if (i < DT_IH * DT_IW * F4) {
                 const int p = i / F4, c = (i % F4) * 4;
-                const int iy = min(max(ty0 + p / DT_IW - 1, 0), H - 1);
-                const int ix = min(max(tx0 + p % DT_IW - 1, 0), W - 1);
-                tv[it] = *reinterpret_cast<const f32x4*>(xi + ((size_t)iy * W + ix) * DT_C +
-                                                         pass * DT_CC + c);
+                const int iy = ty0 + p / DT_IW - 1, ix = tx0 + p % DT_IW - 1;
+                const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                f32x4 v = tv[it];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
+                *reinterpret_cast<f32x4*>(in_s + p * DT_CS + c) = v;
             }
-            __syncthreads();                                        // previous pass / slot consumed
+        }
+        __syncthreads();
+        if (step + 1 < 2 * K) fetch(step + 1);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = t + it * 256;
-                if (i < DT_IH * DT_IW * F4) {
-                    const int p = i / F4, c = (i % F4) * 4;
-                    const int iy = ty0 + p / DT_IW - 1, ix = tx0 + p % DT_IW - 1;
-                    const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                    f32x4 v = tv[it];
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* ip = in_s + ((py + tap / 3) * DT_IW + px + tap % 3) * DT_CS;
+            const float* wt = wq + ((size_t)tap * DT_C + pass * DT_CC) * 4;       // wave-uniform
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = inside ? v[u] : 0.f;
-                    *reinterpret_cast<f32x4*>(in_s + p * DT_CS + c) = v;
-                }
-            }
-            __syncthreads();
+            for (int c4 = 0; c4 < DT_CC / 4; ++c4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(ip + 4 * c4);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float* ip = in_s + ((py + tap / 3) * DT_IW + px + tap % 3) * DT_CS;
-                const float* wt = wq + ((size_t)tap * DT_C + pass * DT_CC) * 4;   // wave-uniform
-#pragma unroll
-                for (int c4 = 0; c4 < DT_CC / 4; ++c4) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(ip + 4 * c4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float* w4 = wt + (4 * c4 + u) * 4;
-                        acc[0] = fmaf(xv[u], w4[0], acc[0]);
-                        acc[1] = fmaf(xv[u], w4[1], acc[1]);
-                        acc[2] = fmaf(xv[u], w4[2], acc[2]);
-                        acc[3] = fmaf(xv[u], w4[3], acc[3]);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const float* w4 = wt + (4 * c4 + u) * 4;
+                    acc[0] = fmaf(xv[u], w4[0], acc[0]);
+                    acc[1] = fmaf(xv[u], w4[1], acc[1]);
+                    acc[2] = fmaf(xv[u], w4[2], acc[2]);
+                    acc[3] = fmaf(xv[u], w4[3], acc[3]);
                 }
             }
         }
-        float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
-        ro[0] = acc[0];
-        ro[HW] = acc[1];
-        ro[2 * HW] = acc[2];
-        alpha_s[k * 256 + t] = acc[3];
+        if (pass == 1) {
+            float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
+            ro[0] = acc[0];
+            ro[HW] = acc[1];
+            ro[2 * HW] = acc[2];
+            alpha_s[k * 256 + t] = acc[3];
+            acc = bv;
+        }
     }
 
     // softmax over slots (exact two-pass, as F.softmax) + compositing
