@@ -216,3 +216,22 @@ def test_training_lr_schedule_matches_reference_driver():
     assert PredictorTrainStep.lr_at(cfg, 0) == 0.0        # the reference's first step runs at lr = 0
     assert PredictorTrainStep.lr_at(cfg, 2000) == pytest.approx(1e-4)
     assert PredictorTrainStep.lr_at(cfg, 2001) == pytest.approx(1e-4)
+
+
+def test_graphed_step_result_is_a_lazy_mapping():
+    """ PredictorTrainStep.step_graphed returns a StepResult: the device snapshot {sum sq slot, sum sq img, grad
+    norm} is read on first access only, keys and arithmetic as the eager step's dict (04_train_predictor.py:96-104
+    logs loss / pred_slot_mse / pred_img_mse) """
+    from textocvp_amd.train.step import StepResult
+
+    class Snap:
+        reads = 0
+
+        def tolist(self):
+            Snap.reads += 1
+            return [8.0, 6.0, 3.5]
+    r = StepResult(Snap(), 0.25, 0.5, 1e-4)
+    assert Snap.reads == 0 and list(r) == ["loss", "pred_slot_mse", "pred_img_mse", "grad_norm", "lr"] and len(r) == 5
+    assert r["pred_slot_mse"] == 2.0 and r["pred_img_mse"] == 3.0 and r["loss"] == 5.0
+    assert r["grad_norm"] == 3.5 and r["lr"] == 1e-4 and dict(r)["loss"] == 5.0
+    assert Snap.reads == 1                                    # one read-back, however often the numbers are used
