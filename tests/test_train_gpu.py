@@ -259,6 +259,58 @@ def test_predictor_rollout_gradients_match_oracle_autograd():
     print(f"predictor BPTT gradients: worst relative error {worst:.2e} over {len(tp.names)} tensors")
 
 
+def test_textocvp_t5_rollout_gradients_with_frozen_text_encoder():
+    """ TextOCVP_T5 (reference text_cond_OCVP.py:141-151: pretrained T5 encoder, freeze_params): the text
+    embeddings come from the frozen encoder (inference kernels, pinned by t5_encoder.npz elsewhere), the predictor
+    blocks train.  Gradients of every trainable tensor against torch.autograd on the oracle's predictor step fed
+    with the same embeddings; the frozen encoder has neither gradients nor optimiser state. """
+    from conftest import load_golden
+    from oracle import slot_rollout_oracle as O
+    from textocvp_amd.setup_model import default_exp_params, setup_predictor
+    from textocvp_amd.train import autograd as ag
+    from textocvp_amd.train.predictor import TrainablePredictor
+    g = load_golden("t5_encoder.npz")
+    exp = default_exp_params(num_slots=7, num_context=1, num_preds=3, predictor_name="TextOCVP_T5")
+    pred = setup_predictor(exp)
+    synth.fill_module_(pred.predictor.text_encoder, prefix="t5.")
+    for part in ("predictor", "mlp_in", "mlp_out", "pe"):
+        synth.fill_module_(getattr(pred.predictor, part), prefix=f"pred.predictor.{part}.")
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    B, P = ids.shape[0], 3
+    hist = synth.synth_tensor("train.hist_t5", (B, 1 + P, 7, 128), "normal")
+    pred = pred.to(DEV)
+    tp = TrainablePredictor(pred)
+    assert tp.frozen_text and not any(n.startswith("predictor.text_encoder.") for n in tp.names)
+    assert len(tp.all_names) > len(tp.names)
+    tape = ag.Tape()
+    preds = tp.rollout(tape, hist.to(DEV), ids.to(DEV), None, P, attn_masks=mask.to(DEV))
+    stacked = ag.stack_frames(tape, preds)
+    target = hist[:, 1:1 + P]
+    total, sc = ag.mse(tape, stacked, target.to(DEV))
+    tape.backward()
+    # reference: the oracle's predictor step on the embeddings the frozen encoder produced here
+    text = pred.encode_text_caption(caption_tokens=ids.to(DEV), attn_masks=mask.to(DEV)).detach().cpu().double()
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in pred.state_dict().items()
+          if not k.startswith("predictor.text_encoder.") and v.dtype.is_floating_point}
+    p = O.sub(sd, "predictor.")
+    window, ref = hist[:, :1].double().clone(), []
+    for t in range(P):
+        cur = O.text_ocvp_step(p, window, text)
+        window = torch.cat([window, cur.unsqueeze(1)], dim=1)
+        ref.append(cur)
+    ref_preds = torch.stack(ref, dim=1)
+    ref_loss = F.mse_loss(ref_preds, target.double())
+    ref_loss.backward()
+    assert abs(total.item() * sc - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    assert rel_err(stacked.data, ref_preds) < 1e-4
+    for name, var in tp.names.items():
+        refg = sd[name].grad
+        if refg is None:
+            assert var.grad is None or var.grad.abs().max().item() == 0.0, name
+            continue
+        assert var.grad is not None and rel_err(var.grad, refg) < 2e-3, name
+
+
 def test_training_step_gradients_with_image_loss_match_oracle_autograd():
     """ the full loss of 04_train_predictor.py (image MSE through the frozen SAVi decoder + slot MSE):
     parameter gradients against torch.autograd on the CPU oracle, then one clipped Adam step
@@ -340,6 +392,40 @@ def _build_step(Ks=7, P=2):
     tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
     noise = synth.synth_noise(2, Ks, 128, seed=1)
     return ts, videos, tokens, lengths, noise
+
+
+def test_textocvp_t5_training_step_eager_and_graphed():
+    """ full optimisation steps of TextOCVP_T5 (frozen T5 encoder, `attn_masks` as in predictor_wrapper.py:101-111):
+    eager and graph-replayed steps agree, only the predictor's own tensors move and carry Adam moments, the
+    optimiser state keeps torch.optim's indices over ALL parameters """
+    from conftest import load_golden
+    from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
+    from textocvp_amd.train.step import PredictorTrainStep
+    g = load_golden("t5_encoder.npz")
+    ids, mask = torch.from_numpy(g["ids"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    B, P, Ks = ids.shape[0], 2, 7
+    res = []
+    for graphed in (False, True):
+        exp = default_exp_params(num_slots=Ks, num_context=1, num_preds=P, predictor_name="TextOCVP_T5")
+        savi, pred = setup_model(exp["model"]).eval(), setup_predictor(exp)
+        synth.fill_module_(savi, prefix="savi.")
+        synth.fill_module_(pred.predictor.text_encoder, prefix="t5.")
+        for part in ("predictor", "mlp_in", "mlp_out", "pe"):      # everything outside the T5 encoder, incl. the learned PE
+            synth.fill_module_(getattr(pred.predictor, part), prefix=f"pred.predictor.{part}.")
+        ts = PredictorTrainStep(savi.to(DEV), pred.to(DEV), lr=1e-4, clip=0.05, warmup_steps=0)
+        t5_before = {n: p.detach().clone() for n, p in pred.named_parameters() if n.startswith("predictor.text_encoder.")}
+        videos = synth.synth_videos(B, 1 + P, seed=0).to(DEV)
+        noise = synth.synth_noise(B, Ks, 128, seed=1).to(DEV)
+        run = ts.step_graphed if graphed else ts.step
+        losses = [dict(run(videos, ids, None, attn_masks=mask, init_noise=noise)) for _ in range(3)]
+        assert all(torch.equal(p, t5_before[n]) for n, p in pred.named_parameters() if n in t5_before)
+        assert set(ts.state) == set(ts.model.names) and not any(n.startswith("predictor.text_encoder.") for n in ts.state)
+        opt = ts.optimizer_state_dict()
+        assert len(opt["param_groups"][0]["params"]) == len(ts.model.all_names) > len(opt["state"])
+        res.append(losses)
+    for a, b in zip(*res):
+        assert abs(a["loss"] - b["loss"]) < 1e-5 * abs(a["loss"]) and a["lr"] == b["lr"]
+    assert res[0][0]["loss"] != res[0][2]["loss"]
 
 
 def test_training_step_against_reference_golden():

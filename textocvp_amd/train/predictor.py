@@ -45,8 +45,13 @@ class TrainablePredictor:
         """
         self.wrapper = wrapper
         self.pred = wrapper.predictor
-        if type(self.pred).__name__ != "TextOCVP_CustomTF":
-            raise NotImplementedError("training step: TextOCVP_CustomTF only (reference config 5)")
+        kind = type(self.pred).__name__
+        if kind not in ("TextOCVP_CustomTF", "TextOCVP_T5"):
+            raise NotImplementedError("training step: TextOCVP_CustomTF / TextOCVP_T5 (the text-conditioned predictors "
+                                      "of the reference's training configs)")
+        # TextOCVP_T5: the pretrained T5 encoder is FROZEN in the reference (freeze_params, text_cond_OCVP.py:
+        # 141-151): its embeddings come from the inference path, nothing back-propagates into it
+        self.frozen_text = kind == "TextOCVP_T5"
         self.precision = precision
         # drop the LayerNorm outputs and MLP hidden activations after their forward use and rebuild them
         # in the backward pass.  Measured at B=32, K=30, 19 predictions: "0" 63.6 GB, "ln" 55.0 GB at no cost in time,
@@ -55,12 +60,16 @@ class TrainablePredictor:
         mode = os.environ.get("TOCVP_TRAIN_RECOMPUTE", "ln")           # "ln" | "mlp" | "all" | "0"
         self.recompute_ln = mode in ("all", "1", "ln")
         self.recompute_mlp = mode in ("all", "1", "mlp")
-        self.text_dropout = float(self.pred.text_encoder.dropout.p if text_dropout is None else text_dropout)
+        self.text_dropout = 0.0 if self.frozen_text else float(
+            self.pred.text_encoder.dropout.p if text_dropout is None else text_dropout)
         self.generator = generator
         self.vars = {}
         self.names = {}
         self.params = {}
+        self.all_names = [name for name, _ in wrapper.named_parameters()]   # torch.optim's parameter order
         for name, p in wrapper.named_parameters():
+            if not p.requires_grad:                  # frozen (the T5 encoder): no gradient, no optimiser state
+                continue
             v = ag.Var(p.data, requires_grad=True, name=name)
             self.vars[id(p)] = v
             self.names[name] = v
@@ -218,11 +227,16 @@ class TrainablePredictor:
         out = self._lin(tape, last, p.mlp_out)
         return ag.add(tape, out, window[-1]) if p.residual else out
 
-    def rollout(self, tape, slot_history, tokens, lengths, num_preds=None):
-        """ PredictorWrapper.forward: returns the list of predicted-slot Vars (B, K, D) """
+    def rollout(self, tape, slot_history, tokens, lengths, num_preds=None, attn_masks=None):
+        """ PredictorWrapper.forward: returns the list of predicted-slot Vars (B, K, D).
+        TextOCVP_T5: ``tokens`` are the T5 input ids and ``attn_masks`` their attention mask (lengths unused). """
         wr = self.wrapper
         num_preds = wr.num_preds if num_preds is None else num_preds
-        text_kv = self.text_kv(tape, self.encode_text(tape, tokens, lengths))
+        if self.frozen_text:
+            text = ag.Var(wr.encode_text_caption(caption_tokens=tokens, attn_masks=attn_masks).contiguous())
+        else:
+            text = self.encode_text(tape, tokens, lengths)
+        text_kv = self.text_kv(tape, text)
         window = [ag.Var(slot_history[:, i].contiguous()) for i in range(wr.num_context)]
         preds = []
         teacher = wr.exp_params["prediction_params"]["teacher_force"]

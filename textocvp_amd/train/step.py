@@ -103,10 +103,12 @@ class PredictorTrainStep:
         if L < nc + npred:
             raise ValueError(f"Seq. length {L} must be >= {nc + npred = }")
         videos = videos[:, :nc + npred]
+        others = dict(others)
+        attn_masks = others.pop("attn_masks", None)              # TextOCVP_T5 (predictor_wrapper.py:101-111)
         hist = self.savi(mode="decomp", x=videos, num_imgs=nc + npred, decode=False, **others)["slot_history"]
         self.model.zero_grad()
         tape = ag.Tape()
-        preds = self.model.rollout(tape, hist, caption_tokens, caption_lengths, npred)
+        preds = self.model.rollout(tape, hist, caption_tokens, caption_lengths, npred, attn_masks=attn_masks)
         stacked = ag.stack_frames(tape, preds)                              # (B, P, K, D)
         Ks, D = stacked.data.shape[2:]
         tgt_slots = hist[:, nc:nc + npred].contiguous()
@@ -209,7 +211,7 @@ class PredictorTrainStep:
     # ---- checkpoint state, in the reference's formats (lib/setup_model.py:176-184, 228-240) --------------
     def optimizer_state_dict(self):
         """ torch.optim.Adam.state_dict() layout over PredictorWrapper.parameters() order """
-        names = list(self.model.names)
+        names = list(self.model.all_names)                    # frozen parameters keep their index, without state
         state = {}
         for i, name in enumerate(names):
             if name in self.state:
@@ -248,7 +250,7 @@ class PredictorTrainStep:
         The model weights are loaded by setup_model.load_checkpoint.
         """
         opt = ckpt["optimizer_state_dict"]
-        names = list(self.model.names)
+        names = list(self.model.all_names)
         steps = 0
         for i, st in opt["state"].items():
             name = names[int(i)]
@@ -287,7 +289,8 @@ class PredictorTrainStep:
         """
         if getattr(self, "_graphs", None) is None:
             warm = self.step(videos, caption_tokens, caption_lengths, **others)   # eager step (fills caches)
-            self._static = [videos.clone(), caption_tokens.clone(), caption_lengths.clone(),
+            self._static = [videos.clone(), caption_tokens.clone(),
+                            None if caption_lengths is None else caption_lengths.clone(),
                             {k: (v.clone() if torch.is_tensor(v) else v) for k, v in others.items()}]
             torch.cuda.synchronize()
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -305,7 +308,8 @@ class PredictorTrainStep:
         sv, st, sl, so = self._static
         sv.copy_(videos)
         st.copy_(caption_tokens)
-        sl.copy_(caption_lengths)
+        if sl is not None:
+            sl.copy_(caption_lengths)
         for k, v in others.items():
             if torch.is_tensor(v):
                 so[k].copy_(v)
