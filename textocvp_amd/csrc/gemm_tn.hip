@@ -9,9 +9,9 @@
 // (v_mfma_f32_32x32x2_f32, A[i][k] / B[k][j] one float per lane) takes lane-consecutive floats of one row,
 // which is a conflict-free ds_read_b32 on the natural row-major tile.
 //
-//   * 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 16 token rows per stage, 4 stages of
-//     16 KiB filled by LDS-DMA (global_load_lds, 16 B per lane) three stages ahead of their use; one barrier
-//     per stage.  Rows are stored in PAIRS: [32-column block][row parity][32 floats], so the two k-slices of
+//   * 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 16 token rows per stage, 3 stages of
+//     16 KiB (4 measured the same, 2 % slower on the MLP shapes) filled by LDS-DMA (global_load_lds, 16 B per
+//     lane) two stages ahead of their use; one barrier per stage.  Rows are stored in PAIRS: [32-column block][row parity][32 floats], so the two k-slices of
 //     an MFMA operand (rows 2s and 2s+1, 32 columns) are 64 consecutive floats = one read per lane, all
 //     64 banks.  The DMA does that interleave on the source side (the LDS side of a DMA is lane-linear).
 //   * split-K over blockIdx.z: split z owns token rows [z * chunk, (z + 1) * chunk) and its own (N x K)
@@ -27,11 +27,14 @@ struct TnArgs {
     int ldg, ldx, M, N, K, chunk, accumulate;
 };
 
-constexpr int TN_T = 128, TN_ROWS = 16, TN_STAGES = 4;
+#ifndef TOCVP_TN_STAGES
+#define TOCVP_TN_STAGES 3
+#endif
+constexpr int TN_T = 128, TN_ROWS = 16, TN_STAGES = TOCVP_TN_STAGES;
 constexpr int TN_OPER = TN_ROWS * TN_T;            // floats per operand tile (8 KiB)
 constexpr int TN_STAGE = 2 * TN_OPER;              // floats per stage
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
+__global__ __launch_bounds__(256, TN_STAGES == 3 ? 3 : 2) void gemm_tn_f32_kernel(TnArgs p) {
     __shared__ __attribute__((aligned(1024))) float lds[TN_STAGES * TN_STAGE];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
     const int d_row = seg & 1, d_col = (seg >> 1) * 32 + (lane & 7) * 4;
     const size_t goff = (size_t)d_row * p.ldg + n0 + d_col, xoff = (size_t)d_row * p.ldx + k0 + d_col;
     auto dma = [&](int it) {
-        float* st = lds + (it & (TN_STAGES - 1)) * TN_STAGE;
+        float* st = lds + (it % TN_STAGES) * TN_STAGE;
         const int row = r_lo + it * TN_ROWS + wave * 4;           // this wave: row pairs 2 * wave, 2 * wave + 1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -84,12 +87,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(TnArgs p) {
     for (int it = 0; it < nit; ++it) {
         // LDS-DMA completion is tracked by vmcnt only; 4 DMA instructions per wave and stage (the older
         // loads of the initial accumulators return in order before them)
-        if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (TN_STAGES == 4 && it + 2 < nit) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (it + 1 < nit) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();              // stage `it` has landed for every wave; stage it - 1 is no longer read
         if (it + TN_STAGES - 1 < nit) dma(it + TN_STAGES - 1);
-        const float* gs = lds + (it & (TN_STAGES - 1)) * TN_STAGE;
+        const float* gs = lds + (it % TN_STAGES) * TN_STAGE;
         const float* xs = gs + TN_OPER;
 #pragma unroll
         for (int s = 0; s < TN_ROWS / 2; ++s) {
