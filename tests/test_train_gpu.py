@@ -634,3 +634,19 @@ def test_bmm_generic(M, N, Kd, tA, tB, ld_pad):
            sA=(nb2 * a_shape[0] * a_shape[1], a_shape[0] * a_shape[1]),
            sB=(nb2 * b_shape[0] * b_shape[1], b_shape[0] * b_shape[1]), sC=(nb2 * M * N, M * N), alpha=0.5, acc=True)
     assert rel_err(Cd, ref) < 1e-5
+
+
+def test_training_first_pass_is_range_checked_and_falls_back():
+    """ weights / activations outside the fp16-plane range (|x| < 255) must not be trained on silently: the first
+    pass is range-checked and the tripping arithmetic moves to its fp32-range fallback (here: a predictor whose
+    input projection is scaled so that the tokens exceed 255) """
+    import warnings
+    ts, videos, tokens, lengths, noise = _build_step()
+    with torch.no_grad():
+        ts.wrapper.predictor.mlp_in.weight.mul_(400.0)
+    ts.model.mark_updated()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = ts.step(videos.to(DEV), tokens.to(DEV), lengths.to(DEV), init_noise=noise.to(DEV))
+    assert ts.model.precision == "bf16x6" and any("fp32-range fallback" in str(x.message) for x in w)
+    assert out["loss"] == out["loss"] and ts._range_ok                      # finite, and checked only once

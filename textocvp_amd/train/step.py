@@ -122,9 +122,45 @@ class PredictorTrainStep:
         self._grads()                                                       # materialise missing gradients
         return sq_slot, sc_slot, sq_img, self.w_img / n_img
 
+    def _range_checked_pass(self, videos, caption_tokens, caption_lengths, others):
+        """
+        The FIRST eager forward + backward (after construction or ``load_training_state``) verifies every operand of
+        the fp16-plane kernels (|activation| < 255, |weight| < 63; they saturate beyond, kernels.TocvpRangeError)
+        and moves the arithmetic that trips to its fp32-exponent-range fallback before anything is trained on a
+        saturated value: predictor GEMMs f16x3 -> bf16x6, attention products -> exact fp32, frozen decoder convs
+        f16x3 -> bf16x3.  Later steps (and the captured graphs) run unchecked, like the inference path after
+        ``calibrate_precision``.
+        """
+        import warnings
+        for _ in range(4):
+            try:
+                with K.check_range(True):
+                    return self._forward_backward(videos, caption_tokens, caption_lengths, others)
+            except K.TocvpRangeError as err:
+                msg = str(err)
+                mod, attr = err.owner if isinstance(err.owner, tuple) and len(err.owner) == 2 else (None, None)
+                table = getattr(type(mod), "range_fallbacks", {}).get(attr) if mod is not None else None
+                if table and getattr(mod, attr, None) in table:          # a module of the inference path (frozen
+                    setattr(mod, attr, table[getattr(mod, attr)])        # SAVi, T5 encoder) named its own knob
+                elif "GEMM" in msg and self.model.precision == "f16x3":
+                    self.model.precision = "bf16x6"
+                elif "attention" in msg and K._ATTN_QK16:
+                    K._ATTN_QK16 = False
+                elif "conv" in msg and self.decoder.dec.conv_precision == "f16x3":
+                    self.decoder.dec.conv_precision = "bf16x3"
+                else:
+                    raise
+                warnings.warn(f"training step: {msg} -- switched that arithmetic to its fp32-range fallback")
+        raise K.TocvpError("training step: operands out of the fp16-plane range after every fallback")
+
     def loss_and_grads(self, videos, caption_tokens, caption_lengths, **others):
         """ forward + backward; leaves the gradients in ``self.model.names[*].grad``; returns the losses """
-        sq_slot, sc_slot, sq_img, sc_img = self._forward_backward(videos, caption_tokens, caption_lengths, others)
+        if not getattr(self, "_range_ok", False):
+            sq_slot, sc_slot, sq_img, sc_img = self._range_checked_pass(videos, caption_tokens, caption_lengths, others)
+            self._range_ok = True
+        else:
+            sq_slot, sc_slot, sq_img, sc_img = self._forward_backward(videos, caption_tokens, caption_lengths,
+                                                                      others)
         loss_slot, loss_img = float(sq_slot.item()) * sc_slot, float(sq_img.item()) * sc_img
         return {"loss": loss_slot + loss_img, "pred_slot_mse": loss_slot, "pred_img_mse": loss_img}
 
@@ -261,6 +297,7 @@ class PredictorTrainStep:
             steps = max(steps, int(float(st["step"])))
         self.iteration = int(ckpt.get("iteration", steps))
         self._graphs = None                                   # moments were re-allocated: re-capture
+        self._range_ok = False                                # new weights: one range-checked pass again
         return self
 
     def apply(self):
