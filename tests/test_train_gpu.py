@@ -311,6 +311,52 @@ def test_textocvp_t5_rollout_gradients_with_frozen_text_encoder():
         assert var.grad is not None and rel_err(var.grad, refg) < 2e-3, name
 
 
+@pytest.mark.parametrize("name", ["VanillaTransformer", "OCVPSeq"])
+def test_unconditioned_predictor_rollout_gradients_match_oracle_autograd(name):
+    """ the unconditioned predictors the reference's trainer also accepts (OCVP.py: joint attention over all
+    (frame, slot) tokens / object attention then time attention): BPTT gradients of every tensor against
+    torch.autograd on the oracle (dropout off = the deterministic gradient), then three full optimisation steps """
+    from oracle import slot_rollout_oracle as O
+    from textocvp_amd.setup_model import default_exp_params, setup_model, setup_predictor
+    from textocvp_amd.train import autograd as ag
+    from textocvp_amd.train.predictor import TrainablePredictor
+    from textocvp_amd.train.step import PredictorTrainStep
+    Ks, P, B = 7, 3, 2
+    exp = default_exp_params(num_slots=Ks, num_context=2, num_preds=P, predictor_name=name)
+    pred = setup_predictor(exp)
+    synth.fill_module_(pred, prefix=f"{name}.")
+    hist = synth.synth_tensor("train.hist_u", (B, 2 + P, Ks, 128), "normal")
+    sd = {k: v.detach().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pred.state_dict().items()}
+    ref_preds = O.rollout(sd, hist.double(), None, None, 2, P, buffer_size=pred.input_buffer_size, kind=name)
+    target = hist[:, 2:2 + P]
+    ref_loss = F.mse_loss(ref_preds, target.double())
+    ref_loss.backward()
+    pred = pred.to(DEV)
+    tp = TrainablePredictor(pred, text_dropout=0.0)
+    tape = ag.Tape()
+    preds = tp.rollout(tape, hist.to(DEV), None, None, P)
+    stacked = ag.stack_frames(tape, preds)
+    total, sc = ag.mse(tape, stacked, target.to(DEV))
+    tape.backward()
+    assert abs(total.item() * sc - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    assert rel_err(stacked.data, ref_preds) < 1e-4
+    for pname, var in tp.names.items():
+        assert var.grad is not None and rel_err(var.grad, sd[pname].grad) < 2e-3, pname
+    # full steps (frozen SAVi + image loss + clipped Adam), with the blocks' own dropout active
+    savi = setup_model(exp["model"]).eval()
+    synth.fill_module_(savi, prefix="savi.")
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    ts = PredictorTrainStep(savi.to(DEV), pred, lr=1e-4, clip=0.05, warmup_steps=0, generator=g)
+    assert ts.model.text_dropout == pytest.approx(0.1)
+    videos = synth.synth_videos(B, 2 + P, seed=0).to(DEV)
+    noise = synth.synth_noise(B, Ks, 128, seed=1).to(DEV)
+    losses = [ts.step(videos, None, None, init_noise=noise)["loss"] for _ in range(3)]
+    assert all(v == v for v in losses) and losses[0] != losses[2]
+    more = [ts.step_graphed(videos, None, None, init_noise=noise)["loss"] for _ in range(3)]    # capture + 2 replays
+    assert all(v == v for v in more) and more[2] < losses[0]
+
+
 def test_training_step_gradients_with_image_loss_match_oracle_autograd():
     """ the full loss of 04_train_predictor.py (image MSE through the frozen SAVi decoder + slot MSE):
     parameter gradients against torch.autograd on the CPU oracle, then one clipped Adam step

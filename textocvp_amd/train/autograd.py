@@ -18,7 +18,8 @@ import torch
 from .. import kernels as K
 
 __all__ = ["Var", "Tape", "linear", "layer_norm", "attention", "attention_unfused", "dropout", "add",
-           "activation", "add_position_rows", "stack_frames", "take_frame", "take_last_tokens", "embedding",
+           "activation", "add_position_rows", "stack_frames", "take_frame", "take_last_tokens", "transpose12",
+           "reshape", "embedding",
            "mask_rows", "mse",
            "accumulate", "bmm"]
 
@@ -561,6 +562,25 @@ def take_last_tokens(tape, x, n):
             g[:, T - n:] = out.grad
             accumulate(x, g)
         tape.record(backward)
+    return out
+
+
+def transpose12(tape, x):
+    """ x (B, a, b, E) -> (B, b, a, E) contiguous copy (data movement); the gradient takes the same way back """
+    out = Var(x.data.transpose(1, 2).contiguous(), x.requires_grad)
+    if out.requires_grad:
+        def backward():
+            if out.grad is not None:
+                accumulate(x, out.grad.transpose(1, 2).contiguous())
+        tape.record(backward)
+    return out
+
+
+def reshape(tape, x, shape):
+    """ view of a contiguous Var under another shape; the gradient is the same storage reshaped back """
+    out = Var(x.data.reshape(shape), x.requires_grad)
+    if out.requires_grad:
+        tape.record(lambda: accumulate(x, out.grad.reshape(x.data.shape)) if out.grad is not None else None)
     return out
 
 

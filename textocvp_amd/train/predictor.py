@@ -46,9 +46,10 @@ class TrainablePredictor:
         self.wrapper = wrapper
         self.pred = wrapper.predictor
         kind = type(self.pred).__name__
-        if kind not in ("TextOCVP_CustomTF", "TextOCVP_T5"):
-            raise NotImplementedError("training step: TextOCVP_CustomTF / TextOCVP_T5 (the text-conditioned predictors "
-                                      "of the reference's training configs)")
+        if kind not in ("TextOCVP_CustomTF", "TextOCVP_T5", "VanillaTransformerPredictor", "OCVPSeq"):
+            raise NotImplementedError(f"training step: no differentiable rollout for predictor {kind!r}")
+        self.kind = kind
+        self.text_conditioned = kind.startswith("TextOCVP")
         # TextOCVP_T5: the pretrained T5 encoder is FROZEN in the reference (freeze_params, text_cond_OCVP.py:
         # 141-151): its embeddings come from the inference path, nothing back-propagates into it
         self.frozen_text = kind == "TextOCVP_T5"
@@ -60,8 +61,13 @@ class TrainablePredictor:
         mode = os.environ.get("TOCVP_TRAIN_RECOMPUTE", "ln")           # "ln" | "mlp" | "all" | "0"
         self.recompute_ln = mode in ("all", "1", "ln")
         self.recompute_mlp = mode in ("all", "1", "mlp")
-        self.text_dropout = 0.0 if self.frozen_text else float(
-            self.pred.text_encoder.dropout.p if text_dropout is None else text_dropout)
+        if self.text_conditioned:
+            self.text_dropout = 0.0 if self.frozen_text else float(
+                self.pred.text_encoder.dropout.p if text_dropout is None else text_dropout)
+        else:           # the unconditioned predictors: dropout of their nn.TransformerEncoderLayer blocks (0.1)
+            layer = self.pred.transformer_encoders[0]
+            layer = getattr(layer, "object_encoder_block", layer)
+            self.text_dropout = float(layer.dropout.p if text_dropout is None else text_dropout)
         self.generator = generator
         self.vars = {}
         self.names = {}
@@ -148,6 +154,54 @@ class TrainablePredictor:
             x.release()
         return y
 
+    def _prenorm_layer(self, tape, x, layer, heads):
+        """ nn.TransformerEncoderLayer(norm_first=True, batch_first=True, relu) in training mode (the blocks of the
+        unconditioned predictors, OCVP.py:60-75): x (N, T, E).  Dropout (p of the layer; 0 = eval-mode gradient) on
+        the attention probabilities, after both sub-layers and inside the feed-forward. """
+        pd, gen = self.text_dropout, self.generator
+        E = x.data.shape[-1]
+        sa = layer.self_attn
+        h = self._ln(tape, x, layer.norm1)
+        qkv = ag.linear(tape, h, self.V(sa.in_proj_weight), self.V(sa.in_proj_bias), precision=self.precision)
+        q, k, v = _split_last(tape, qkv, 3)
+        if pd > 0.0:
+            a = ag.attention_unfused(tape, q, k, v, heads, (E // heads) ** -0.5, p_drop=pd, generator=gen)
+            x = ag.add(tape, ag.dropout(tape, self._lin(tape, a, sa.out_proj), pd, generator=gen), x)
+            h = ag.dropout(tape, self._lin(tape, self._ln(tape, x, layer.norm2), layer.linear1, act=K.ACT_RELU), pd,
+                           generator=gen)
+            return ag.add(tape, ag.dropout(tape, self._lin(tape, h, layer.linear2), pd, generator=gen), x)
+        a = ag.attention(tape, q, k, v, heads, (E // heads) ** -0.5)
+        x = self._lin(tape, a, sa.out_proj, residual=x)
+        h = self._lin(tape, self._ln(tape, x, layer.norm2), layer.linear1, act=K.ACT_RELU)
+        return self._lin(tape, h, layer.linear2, residual=x)
+
+    def step_unconditioned(self, tape, window):
+        """ VanillaTransformerPredictor.forward (OCVP.py:100-132) / OCVPSeq.forward (:222-254, layer :301-320) """
+        p = self.pred
+        w = len(window)
+        slots = ag.stack_frames(tape, window)                                   # (B, w, K, D)
+        B, _, Ks, _ = slots.data.shape
+        tokens = self._lin(tape, slots, p.mlp_in)                               # (B, w, K, E)
+        E = tokens.data.shape[-1]
+        if p._pe.device != tokens.data.device:
+            p._pe = p._pe.to(tokens.data.device)
+        tokens = ag.add_position_rows(tape, tokens, ag.Var(p._pe.contiguous()), list(range(w)))   # sinusoid, not flipped
+        if self.kind == "VanillaTransformerPredictor":
+            x = ag.reshape(tape, tokens, (B, w * Ks, E))
+            for layer in p.transformer_encoders:
+                x = self._prenorm_layer(tape, x, layer, p.nhead)
+            last = ag.take_last_tokens(tape, x, Ks)
+        else:
+            x = tokens
+            for layer in p.transformer_encoders:
+                x = self._prenorm_layer(tape, ag.reshape(tape, x, (B * w, Ks, E)), layer.object_encoder_block, p.nhead)
+                x = ag.transpose12(tape, ag.reshape(tape, x, (B, w, Ks, E)))            # (B, K, w, E)
+                x = self._prenorm_layer(tape, ag.reshape(tape, x, (B * Ks, w, E)), layer.time_encoder_block, p.nhead)
+                x = ag.transpose12(tape, ag.reshape(tape, x, (B, Ks, w, E)))            # (B, w, K, E)
+            last = ag.take_last_tokens(tape, ag.reshape(tape, x, (B, w * Ks, E)), Ks)
+        out = self._lin(tape, last, p.mlp_out)
+        return ag.add(tape, out, window[-1]) if p.residual else out
+
     def text_kv(self, tape, text):
         """ per layer: cross-attention keys / values of the caption.  They do not depend on the rollout step,
         so they are projected ONCE per sequence (as the inference path does, BaseTextOCVP.prepare_text); every
@@ -232,16 +286,18 @@ class TrainablePredictor:
         TextOCVP_T5: ``tokens`` are the T5 input ids and ``attn_masks`` their attention mask (lengths unused). """
         wr = self.wrapper
         num_preds = wr.num_preds if num_preds is None else num_preds
-        if self.frozen_text:
-            text = ag.Var(wr.encode_text_caption(caption_tokens=tokens, attn_masks=attn_masks).contiguous())
-        else:
-            text = self.encode_text(tape, tokens, lengths)
-        text_kv = self.text_kv(tape, text)
+        text_kv = None
+        if self.text_conditioned:
+            if self.frozen_text:
+                text = ag.Var(wr.encode_text_caption(caption_tokens=tokens, attn_masks=attn_masks).contiguous())
+            else:
+                text = self.encode_text(tape, tokens, lengths)
+            text_kv = self.text_kv(tape, text)
         window = [ag.Var(slot_history[:, i].contiguous()) for i in range(wr.num_context)]
         preds = []
         teacher = wr.exp_params["prediction_params"]["teacher_force"]
         for t in range(num_preds):
-            cur = self.step(tape, window, text_kv)
+            cur = self.step(tape, window, text_kv) if self.text_conditioned else self.step_unconditioned(tape, window)
             nxt = ag.Var(slot_history[:, wr.num_context + t].contiguous()) if teacher else cur
             window = (window + [nxt])[-wr.input_buffer_size:]
             preds.append(cur)

@@ -326,7 +326,7 @@ class PredictorTrainStep:
         """
         if getattr(self, "_graphs", None) is None:
             warm = self.step(videos, caption_tokens, caption_lengths, **others)   # eager step (fills caches)
-            self._static = [videos.clone(), caption_tokens.clone(),
+            self._static = [videos.clone(), None if caption_tokens is None else caption_tokens.clone(),
                             None if caption_lengths is None else caption_lengths.clone(),
                             {k: (v.clone() if torch.is_tensor(v) else v) for k, v in others.items()}]
             torch.cuda.synchronize()
@@ -344,7 +344,8 @@ class PredictorTrainStep:
             return warm                        # capturing records kernels, it does not run them
         sv, st, sl, so = self._static
         sv.copy_(videos)
-        st.copy_(caption_tokens)
+        if st is not None:
+            st.copy_(caption_tokens)
         if sl is not None:
             sl.copy_(caption_lengths)
         for k, v in others.items():
