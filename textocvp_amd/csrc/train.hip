@@ -287,29 +287,33 @@ __global__ __launch_bounds__(256) void conv3x3_t4_kernel(const float* __restrict
     }
     __syncthreads();
     const int cq = C / 4;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix_total * cq) return;
-    const long pix = i / cq;
-    const int c4 = (int)(i % cq) * 4;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // grid-stride: a workgroup keeps its LDS copy of the weights for many pixels (2.65 -> 2.23 ms per 2040 slot
+    // images).  What remains is the LDS: 36 ds_read_b128 of weights per 144 FMAs.  A lane-per-channel variant with the
+    // weights in registers and the dy quads as scalar loads was measured at 3.2 ms (one pixel per trip leaves the
+    // scalar-load latency uncovered); a row-strip version of it is the next step.
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix_total * cq; i += (long)gridDim.x * 256) {
+        const long pix = i / cq;
+        const int c4 = (int)(i % cq) * 4;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
+        for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const int yy = y + 1 - ty, xx = x + 1 - tx;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix + (long)(yy - y) * W + (xx - x)) * 4);
+            for (int tx = 0; tx < 3; ++tx) {
+                const int yy = y + 1 - ty, xx = x + 1 - tx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix + (long)(yy - y) * W + (xx - x)) * 4);
 #pragma unroll
-            for (int co = 0; co < 4; ++co) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((ty * 3 + tx) * 4 + co) * C + c4);
-                acc += wv * g[co];
+                for (int co = 0; co < 4; ++co) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((ty * 3 + tx) * 4 + co) * C + c4);
+                    acc += wv * g[co];
+                }
             }
-        }
-    const f32x4 a = *reinterpret_cast<const f32x4*>(act + pix * C + c4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(act + pix * C + c4);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = a[u] > 0.f ? acc[u] : 0.f;
-    *reinterpret_cast<f32x4*>(dx + pix * C + c4) = acc;
+        for (int u = 0; u < 4; ++u) acc[u] = a[u] > 0.f ? acc[u] : 0.f;
+        *reinterpret_cast<f32x4*>(dx + pix * C + c4) = acc;
+    }
 }
 
 // Collapsed decoder layer 0: x_in[n,p,:] = relu(cpos[p,:] + S[n, cls(p), :]).
@@ -473,7 +477,8 @@ extern "C" int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float
     if (!tocvp_aligned16(dy) || !tocvp_aligned16(act) || !tocvp_aligned16(dx)) return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     const long npix = (long)nimg * H * W;
-    hipLaunchKernelGGL(conv3x3_t4_kernel, dim3(blocks256(npix * (C / 4))), dim3(256), 0,
+    const long want = (npix * (C / 4) + 255) / 256;
+    hipLaunchKernelGGL(conv3x3_t4_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dy, w, act, dx, npix, H, W, C);
     return tocvp_launch_status();
 }
