@@ -160,13 +160,16 @@ int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const
  * fused (B,N,2D) projection); updates:(B,Ks,D).  attn_out (may be NULL): (B,Ks,N) = attn after
  * "+eps" (SlotAttention.attention_masks side effect, attention.py:101).
  * Ks <= 32, D == 128, N % 32 == 0.  ws: workspace of tocvp_slot_attn_ws_bytes(B,N) bytes, 16-byte aligned
- * (ticket words + one 16.5 KB partial record per workgroup).
- * ONE launch (+ a memset node for the ticket words): k and v are streamed exactly once with coalesced
+ * (ticket words + one 16.5 KB partial record per workgroup).  The ticket words must be ZERO on entry
+ * (tocvp_slot_attn_ws_init once after allocation, or whenever B changes) and are zero again on return: the
+ * last-arriving workgroup of a sample resets its word, so iterations need no memset between them.
+ * ONE launch: k and v are streamed exactly once with coalesced
  * 16-byte loads, both contractions run on the f16 matrix cores with split fp16 operands (fp32-class,
  * valid for |q * scale|, |k|, |v| < 255), the last-arriving workgroup of a sample adds the partial
  * records in a fixed order (deterministic) and renormalises.
  * ------------------------------------------------------------------------------------------- */
 size_t tocvp_slot_attn_ws_bytes(int B, int N);
+int tocvp_slot_attn_ws_init(void* ws, size_t ws_bytes, void* stream);
 int tocvp_slot_attn_iter_f32(const float* q, const float* k, const float* v, int ldkv,
                              float* updates, float* attn_out, int B, int Ks, int N, int D,
                              float scale, float eps, void* ws, size_t ws_bytes, void* stream);

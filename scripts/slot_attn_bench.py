@@ -8,7 +8,7 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 128, 256]:
     q = synth.synth_tensor("b.q", (B, Ks, D), "normal").cuda()
     kv = synth.synth_tensor("b.kv", (B, N, 2 * D), "normal").cuda()
     k, v = kv[..., :D], kv[..., D:]
-    ws = torch.empty((K.lib().tocvp_slot_attn_ws_bytes(B, N) + 3) // 4, device="cuda")
+    ws = K.slot_attn_workspace(B, N, "cuda")
     X = kv * 256.0
     hi = X.half()
     planes = torch.stack([hi, (X - hi.float()).half()], dim=2).contiguous()

@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256, 1) void slot_attn_kernel(SaArgs p) {
             if (is_last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+                p.cnt[b] = 0;       // self-cleaning: nobody else touches this word any more in this launch, and the
+            }                       // next launch finds it zero without a memset node in front of every iteration
             *flag = is_last;
         }
         __syncthreads();
@@ -397,10 +398,14 @@ extern "C" int tocvp_slot_attn_iter_f32(const float* q, const float* k, const fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned* cnt = static_cast<unsigned*>(ws);
     float* rec = reinterpret_cast<float*>(static_cast<char*>(ws) + cnt_bytes(B));
-    if (nrec > 1 && hipMemsetAsync(cnt, 0, cnt_bytes(B), s) != hipSuccess) return TOCVP_ELAUNCH;
     SaArgs p{q, k, v, ldkv, attn_out, rec, cnt, updates, B, Ks, N, tpw, nrec, scale, eps};
     hipLaunchKernelGGL(slot_attn_kernel<false>, dim3(nrec, B), dim3(256), 0, s, p);
     return tocvp_launch_status();
+}
+
+extern "C" int tocvp_slot_attn_ws_init(void* ws, size_t ws_bytes, void* stream) {
+    TOCVP_CHECK_ARG(ws && ws_bytes > 0);
+    return hipMemsetAsync(ws, 0, ws_bytes, static_cast<hipStream_t>(stream)) == hipSuccess ? TOCVP_OK : TOCVP_ELAUNCH;
 }
 
 extern "C" int tocvp_slot_attn_iter_planes_f32(const float* q, const void* kv_planes, float* updates,
@@ -418,7 +423,6 @@ extern "C" int tocvp_slot_attn_iter_planes_f32(const float* q, const void* kv_pl
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned* cnt = static_cast<unsigned*>(ws);
     float* rec = reinterpret_cast<float*>(static_cast<char*>(ws) + cnt_bytes(B));
-    if (nrec > 1 && hipMemsetAsync(cnt, 0, cnt_bytes(B), s) != hipSuccess) return TOCVP_ELAUNCH;
     // one plane row = 1 KiB = 256 floats: the kernel's row arithmetic is in floats
     SaArgs p{q, static_cast<const float*>(kv_planes), nullptr, 256, attn_out, rec, cnt, updates, B, Ks, N, tpw,
              nrec, scale, eps};

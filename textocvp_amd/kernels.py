@@ -73,6 +73,7 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_slot_attn_ws_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "tocvp_slot_attn_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tocvp_slot_attn_iter_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -623,6 +624,15 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     return o
 
 
+def slot_attn_workspace(B, N, device):
+    """ workspace of the slot-attention kernel for THIS (B, N): ticket words zeroed once (tocvp_slot_attn_ws_init);
+    every iteration leaves them zero again, so the same tensor serves all iterations of that shape """
+    need = lib().tocvp_slot_attn_ws_bytes(B, N)
+    ws = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+    _check(lib().tocvp_slot_attn_ws_init(_ptr(ws), ws.numel() * 4, _stream()), "tocvp_slot_attn_ws_init")
+    return ws
+
+
 def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
     """ q (B, Ks, D); k, v (B, N, D) views with row stride ldkv -> updates (B, Ks, D). """
     B, Ks, D = q.shape
@@ -631,9 +641,9 @@ def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
     assert q.is_contiguous()
     assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
     assert k.stride(0) == N * k.stride(1) and v.stride(0) == N * v.stride(1)
-    need = lib().tocvp_slot_attn_ws_bytes(B, N)
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((need + 3) // 4, device=q.device, dtype=torch.float32)
+    if ws is None:
+        ws = slot_attn_workspace(B, N, q.device)
+    assert ws.numel() * 4 >= lib().tocvp_slot_attn_ws_bytes(B, N)
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
     # units = algorithmic HBM bytes: k and v read once (B * 2 * N * D * sizeof)
     _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
@@ -654,9 +664,9 @@ def slot_attn_iter_planes(q, kv_planes, scale, eps, attn_out=None, ws=None):
     _dev_f32(q, "q")
     assert q.is_contiguous() and kv_planes.is_contiguous() and kv_planes.dtype == torch.float16
     assert tuple(kv_planes.shape) == (B, N, 2, 2 * D), (kv_planes.shape, (B, N, 2, 2 * D))
-    need = lib().tocvp_slot_attn_ws_bytes(B, N)
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((need + 3) // 4, device=q.device, dtype=torch.float32)
+    if ws is None:
+        ws = slot_attn_workspace(B, N, q.device)
+    assert ws.numel() * 4 >= lib().tocvp_slot_attn_ws_bytes(B, N)
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
     _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
         lib().tocvp_slot_attn_iter_planes_f32(_ptr(q), _ptr(kv_planes), _ptr(upd), _ptr(attn_out), B, Ks, N, D,

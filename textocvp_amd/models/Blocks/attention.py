@@ -135,9 +135,8 @@ class SlotAttention(nn.Module):
             kv = kv.planes.view(*kv.shape[:-1], 2, kv.shape[-1])
         planes = kv.dtype == torch.float16
         N = kv.shape[1]
-        need = K.lib().tocvp_slot_attn_ws_bytes(B, N)
-        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != slots.device:
-            self._ws = torch.empty((need + 3) // 4, device=slots.device, dtype=torch.float32)
+        if self._ws is None or self._ws_key != (B, N, slots.device):          # ticket words zeroed once per shape
+            self._ws, self._ws_key = K.slot_attn_workspace(B, N, slots.device), (B, N, slots.device)
         attn = None
         for _ in range(num_iters):
             prev = slots
