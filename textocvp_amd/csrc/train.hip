@@ -286,33 +286,48 @@ __global__ __launch_bounds__(256) void conv3x3_t4_kernel(const float* __restrict
         ws[i] = w[((size_t)co * C + c) * 9 + tap];
     }
     __syncthreads();
-    const int cq = C / 4;
-    // grid-stride: a workgroup keeps its LDS copy of the weights for many pixels (2.65 -> 2.23 ms per 2040 slot
-    // images).  What remains is the LDS: 36 ds_read_b128 of weights per 144 FMAs.  A lane-per-channel variant with the
-    // weights in registers and the dy quads as scalar loads was measured at 3.2 ms (one pixel per trip leaves the
-    // scalar-load latency uncovered); a row-strip version of it is the next step.
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix_total * cq; i += (long)gridDim.x * 256) {
-        const long pix = i / cq;
+    const int cq = C / 4, wq = W / 4;
+    // Item = (4 consecutive pixels of a row, 4 channels): one 16-byte LDS read of weights feeds 16 FMAs (four
+    // pixels) instead of 4 -- with one pixel per item the kernel was bound by those reads (36 ds_read_b128 per 144
+    // FMAs, 2.65 ms per 2040 slot images; grid-stride workgroups that keep their weight image: 2.23 ms).
+    const long nitem = npix_total / 4 * cq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitem; i += (long)gridDim.x * 256) {
+        const long quad = i / cq;                                  // pixel quad: pixels 4 * quad .. + 3
         const int c4 = (int)(i % cq) * 4;
-        const int x = (int)(pix % W), y = (int)((pix / W) % H);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int x0 = (int)(quad % wq) * 4, y = (int)((quad / wq) % H);
+        const long pix0 = quad * 4;
+        f32x4 acc[4];
 #pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const int yy = y + 1 - ty, xx = x + 1 - tx;
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix + (long)(yy - y) * W + (xx - x)) * 4);
+        for (int ty = 0; ty < 3; ++ty) {
+            const int yy = y + 1 - ty;
+            if (yy < 0 || yy >= H) continue;
+            // dy of the six columns x0 - 1 .. x0 + 4 of row yy (zero outside the image)
+            f32x4 g[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xx = x0 - 1 + j;
+                g[j] = (xx >= 0 && xx < W) ? *reinterpret_cast<const f32x4*>(dy + (pix0 + (long)(yy - y) * W + (xx - x0)) * 4)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                 for (int co = 0; co < 4; ++co) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((ty * 3 + tx) * 4 + co) * C + c4);
-                    acc += wv * g[co];
-                }
-            }
-        const f32x4 a = *reinterpret_cast<const f32x4*>(act + pix * C + c4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = a[u] > 0.f ? acc[u] : 0.f;
-        *reinterpret_cast<f32x4*>(dx + pix * C + c4) = acc;
+                    for (int q = 0; q < 4; ++q) acc[q] += wv * g[q + 2 - tx][co];      // pixel x0 + q reads column x0 + q + 1 - tx
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(act + (pix0 + q) * C + c4);
+            f32x4 o = acc[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = a[u] > 0.f ? o[u] : 0.f;
+            *reinterpret_cast<f32x4*>(dx + (pix0 + q) * C + c4) = o;
+        }
     }
 }
 
@@ -477,7 +492,8 @@ extern "C" int tocvp_conv3x3_t4_f32(const float* dy, const float* w, const float
     if (!tocvp_aligned16(dy) || !tocvp_aligned16(act) || !tocvp_aligned16(dx)) return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     const long npix = (long)nimg * H * W;
-    const long want = (npix * (C / 4) + 255) / 256;
+    TOCVP_CHECK_ARG((W & 3) == 0);
+    const long want = (npix / 4 * (C / 4) + 255) / 256;
     hipLaunchKernelGGL(conv3x3_t4_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dy, w, act, dx, npix, H, W, C);
     return tocvp_launch_status();
