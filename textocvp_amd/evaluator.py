@@ -59,9 +59,11 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
                              decode=False, **others)
     slot_history = out_model["slot_history"]
     if overlap_decode is None:
-        # "auto": only below ~96 sequences.  With more, the rollout's GEMMs fill the chip on their own
-        # and the overlap buys nothing (measured at B=128: 3924 vs 3927 frames/s) while every kernel's
-        # duration gets inflated by the sharing.
+        # "auto": only below ~96 sequences.  With more, the rollout's GEMMs fill the chip on their own and
+        # the overlap buys little (round 2 kernels at B=128: 3490 vs 3390-3450 frames/s, +2-3 %; B=64: +1.3 %)
+        # while every kernel's duration gets inflated by the sharing (the decoder conv reads 318 instead of
+        # 425-435 TFLOP/s in situ), which would blur the per-kernel roofline the bench reports.
+        # TOCVP_OVERLAP_DECODE=1 takes the extra throughput.
         mode = os.environ.get("TOCVP_OVERLAP_DECODE", "auto")
         overlap_decode = (B < 96) if mode == "auto" else mode != "0"
     if not (overlap_decode and slot_history.is_cuda):
