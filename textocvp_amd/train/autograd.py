@@ -237,7 +237,7 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
         # Large, aligned shapes run on the split-operand GEMM of the forward pass (bf16x6: fp32-class and,
         # unlike the fp16 planes, with the fp32 exponent range that small gradients need); the operands
         # it wants transposed are copied (data movement).  Everything else takes the generic fp32 kernel.
-        fast = M >= 1024 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
+        fast = M >= 256 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
         tn = _TN and W.requires_grad and M >= 256 and M % 16 == 0 and N % 128 == 0 and Kd % 128 == 0
         if tn:                                            # dW and db in one transpose-free launch
             _weight_grad_tn(tape, W, b, g, x2)
