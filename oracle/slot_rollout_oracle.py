@@ -220,6 +220,22 @@ def savi_decode(sd, slots, resolution=(64, 64), in_channels=3):
     return (recons * masks).sum(dim=1), recons, masks
 
 
+def forward_eval_decomp(sd, videos, noise):
+    """
+    Decomposition-only evaluation, 03_evaluate_decomp_model.py:22-46: SAVi(x=videos, num_imgs=L) with the
+    default mode "decomp" / decode=True (models/SAVi.py:139-223: every frame's corrector slots are decoded),
+    then recons_imgs.clamp(0, 1).  Returns dict(recons_imgs (B, L, 3, H, W) unclamped, recons_objs
+    (B, L, K, 3, H, W), masks (B, L, K, 1, H, W), slot_history (B, L, K, D), recons_clamped).
+    """
+    B, L = videos.shape[:2]
+    hist = savi_decomp(sd, videos, noise, L)
+    imgs, recons, masks = savi_decode(sd, hist.reshape(B * L, *hist.shape[2:]), tuple(videos.shape[-2:]))
+    imgs = imgs.reshape(B, L, *imgs.shape[1:])
+    return {"recons_imgs": imgs, "recons_objs": recons.reshape(B, L, *recons.shape[1:]),
+            "masks": masks.reshape(B, L, *masks.shape[1:]), "slot_history": hist,
+            "recons_clamped": imgs.clamp(0, 1)}
+
+
 # ------------------------------------------------------------------------------------------------
 # ExtendedDINOSAUR, downstream of the ViT backbone  (models/ExtendedDINOSAUR.py, decoders.py:203-365)
 # ------------------------------------------------------------------------------------------------

@@ -280,6 +280,28 @@ def parity_fixtures(out_dir):
 
 
 @torch.no_grad()
+def decomp_fixtures(out_dir):
+    """
+    Decomposition-only evaluation (03_evaluate_decomp_model.py:22-46): ``model(x=videos, num_imgs=L)`` with
+    the default ``mode`` / ``decode=True`` on config-1 shapes (K=7, B=2, L=5), "undamped" SAVi family (O(1)
+    RGB head: nothing attenuates pixel errors).  Stored: the rendered frames (B, L, 3, H, W) unclamped, the
+    masks of sample 0 (all frames, full resolution), the per-slot reconstructions of sample 1's last frame,
+    the slot history and the argmax_K(masks) map of every frame.
+    """
+    savi, _ = build_reference(num_slots=7, num_context=1, num_preds=4, savi_family="undamped")
+    videos = synth.synth_videos(2, 5, seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    with FixedNoise(noise):
+        out = savi(x=videos, num_imgs=videos.shape[1], caption=["a", "b"])      # kwargs as unwrap_batch_data yields
+    fx = {"recons_imgs": out["recons_imgs"].numpy(), "masks_s0": out["masks"][0].numpy(),
+          "recons_objs_s1f4": out["recons_objs"][1, 4].numpy(), "slot_history": out["slot_history"].numpy(),
+          "masks_argmax": out["masks"].argmax(dim=2).to(torch.uint8).numpy()}
+    np.savez(os.path.join(out_dir, "decomp_c1.npz"), **fx)
+    print("decomp_c1:", {k: v.shape for k, v in fx.items()},
+          "recons range", float(out["recons_imgs"].min()), float(out["recons_imgs"].max()))
+
+
+@torch.no_grad()
 def uncond_fixtures(out_dir):
     """ VanillaTransformer / OCVPSeq (models/Predictors/OCVP.py): one step + a 4-step rollout, K=7 """
     import_reference()
@@ -423,7 +445,7 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "uncond", "dinosaur", "t5", "train"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "decomp", "uncond", "dinosaur", "t5", "train"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -432,6 +454,8 @@ if __name__ == "__main__":
         e2e_fixtures(HERE)
     if "parity" in what:
         parity_fixtures(HERE)
+    if "decomp" in what:
+        decomp_fixtures(HERE)
     if "uncond" in what:
         uncond_fixtures(HERE)
     if "dinosaur" in what:

@@ -235,3 +235,37 @@ def test_graphed_step_result_is_a_lazy_mapping():
     assert r["pred_slot_mse"] == 2.0 and r["pred_img_mse"] == 3.0 and r["loss"] == 5.0
     assert r["grad_norm"] == 3.5 and r["lr"] == 1e-4 and dict(r)["loss"] == 5.0
     assert Snap.reads == 1                                    # one read-back, however often the numbers are used
+
+
+def test_dataparallel_replication_is_refused():
+    """ nn.DataParallel over several devices shallow-copies modules per forward; the mirrors hold per-device
+    caches (derived weights, caption K/V, kernel workspaces), so replication raises instead of sharing them """
+    exp = default_exp_params(num_slots=7)
+    for m in (setup_model(exp["model"]), setup_predictor(exp)):
+        with pytest.raises(RuntimeError, match="one process per visible GPU"):
+            m._replicate_for_data_parallel()
+        # a single-device wrapper never replicates: construction and attribute access as in baseEvaluator.py
+        dp = torch.nn.DataParallel(m.eval(), device_ids=None)
+        assert dp.module is m
+
+
+def test_dropin_alias_package_resolves_the_reference_imports():
+    """ PYTHONPATH=<repo>/dropin:<repo>: every `from models.X import Y` of the reference's lib/setup_model.py:43-127,
+    base/basePredictorTrainer.py:20 and data/*.py resolves to the textocvp_amd.models module OBJECTS (zero-edit) """
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "from models.SAVi import SAVi\n"
+        "from models.ExtendedDINOSAUR import ExtendedDINOSAUR\n"
+        "from models.Predictors.OCVP import VanillaTransformerPredictor, OCVPSeq\n"
+        "from models.Predictors.text_cond_OCVP import TextOCVP_CustomTF, TextOCVP_T5\n"
+        "from models.Predictors.predictor_wrapper import PredictorWrapper\n"
+        "from models.Blocks.model_utils import freeze_params\n"
+        "from models.EncodersDecoders.text_encoders import CustomTokenizer\n"
+        "import models, textocvp_amd.models.SAVi as S, textocvp_amd.models.Predictors.predictor_wrapper as W\n"
+        "assert SAVi is S.SAVi and PredictorWrapper is W.PredictorWrapper and models.__name__ == 'textocvp_amd.models'\n"
+        "print('alias ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), root]))
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "alias ok" in res.stdout, res.stderr[-2000:]

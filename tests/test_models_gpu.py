@@ -50,21 +50,49 @@ def gpu(t):
     return t.to(DEV)
 
 
-def assert_same_slot_assignment(masks, ref_argmax, tol=1e-4):
+ARGMAX_REPORT = {}                    # name -> {"pixels", "differ", "max_margin"}; dumped for profiles/r03_parity_by_mode.md
+
+
+def slot_assignment_diff(masks, ref_argmax, name):
     """
-    Slot-index permutation check: argmax_K(masks) must equal the reference map at every pixel
-    whose decision margin (top-1 minus top-2 mask value) exceeds twice the numeric tolerance;
-    pixels inside that margin are genuine ties at the 1e-4 bar and may resolve either way.
-    In exact-fp32 mode the maps are identical (asserted by the fp32 run of this suite).
+    Slot-index permutation check (north star: "slot-index permutation bit-exact"): number of pixels whose
+    argmax_K(masks) differs from the reference map, and the top-1 minus top-2 mask margin at those pixels.
+    masks (F, K, 1, H, W); every call is recorded in ARGMAX_REPORT / gpurun_out/r03_argmax_report.json.
     """
     am = masks.argmax(dim=1).cpu()
     ref = torch.as_tensor(ref_argmax).to(am.dtype).reshape(am.shape)
     diff = am != ref
-    if diff.any():
+    n = int(diff.sum())
+    margins = torch.zeros(0)
+    if n:
         top2 = masks.topk(2, dim=1).values.cpu()
-        margin = (top2[:, 0] - top2[:, 1])
-        assert float(margin[diff].max()) < 2 * tol, "slot-index permutation differs beyond a tie"
-        assert float(diff.float().mean()) < 1e-3
+        margins = (top2[:, 0] - top2[:, 1])[diff]
+    mode = os.environ.get("TOCVP_PRECISION", "default")
+    ARGMAX_REPORT[f"{name} [{mode}]"] = {"pixels": diff.numel(), "differ": n,
+                                         "max_margin": float(margins.max()) if n else 0.0}
+    print(f"argmax_K(masks) {name} [{mode}]: {n} of {diff.numel()} pixels differ"
+          + (f", margins {[f'{m:.1e}' for m in margins.tolist()[:8]]}" if n else ""))
+    try:
+        import json
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "r03_argmax_report.json"), "w") as f:
+            json.dump(ARGMAX_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return n, margins
+
+
+def assert_same_slot_assignment(masks, ref_argmax, name, ties=0, tie_margin=1e-6):
+    """
+    ZERO differing pixels, except ``ties`` pixels NAMED by the calling test: pixels where the reference's own
+    top-2 masks are equal to within a few fp32 ulps (``tie_margin``), so that two fp32 evaluation orders on
+    the CPU already disagree (tests/test_oracle_golden.py::test_decomp_only_eval_c1 pins one such pixel between
+    the reference and the oracle).  No tolerance band beyond that.
+    """
+    n, margins = slot_assignment_diff(masks, ref_argmax, name)
+    assert n <= ties, f"{name}: {n} argmax pixels differ from the reference (allowed: {ties} named ties)"
+    if n:
+        assert float(margins.max()) < tie_margin, f"{name}: differing pixel with margin {float(margins.max()):.2e}"
 
 
 @torch.no_grad()
@@ -176,7 +204,7 @@ def test_parity_family_undamped_k30_full_resolution():
         # the 19-step rollout itself deviates by ~1e-5 on pred_slots (same in every decoder mode); its
         # image of that through the O(1) head is part of the e2e figures, hence the full bar there
         assert err < (1e-4 if name.startswith("c2_") else PARITY_TOL), (name, err)
-    assert_same_slot_assignment(e2e["masks"], g["undamped_c2_masks_argmax"])
+    assert_same_slot_assignment(e2e["masks"], g["undamped_c2_masks_argmax"], "e2e config 2, undamped family (parity_k30)")
 
 
 @torch.no_grad()
@@ -193,7 +221,7 @@ def test_e2e_config1_against_reference_golden(k7):
     assert max_abs(out["slot_history"].cpu(), g["slot_history"]) < 1e-4
     assert max_abs(out["pred_slots"].cpu(), g["pred_slots"]) < 1e-4
     assert max_abs(out["pred_imgs"].cpu(), g["pred_imgs"]) < 1e-4
-    assert_same_slot_assignment(out["masks"], g["masks_argmax"])
+    assert_same_slot_assignment(out["masks"], g["masks_argmax"], "e2e config 1 (e2e_c1)")
 
 
 @torch.no_grad()
@@ -209,7 +237,7 @@ def test_e2e_config2_against_reference_golden(k30):
     assert max_abs(out["slot_history"].cpu(), g["slot_history"]) < 1e-4
     assert max_abs(out["pred_slots"].cpu(), g["pred_slots"]) < 1e-4
     assert max_abs(out["pred_imgs"][..., ::2, ::2].cpu(), g["pred_imgs_sub2"]) < 1e-4
-    assert_same_slot_assignment(out["masks"][..., ::2, ::2], g["masks_argmax_sub2"])
+    assert_same_slot_assignment(out["masks"][..., ::2, ::2], g["masks_argmax_sub2"], "e2e config 2 (e2e_c2, every 2nd pixel)")
 
 
 @torch.no_grad()
@@ -324,7 +352,7 @@ def test_e2e_against_oracle_fresh_inputs(k7):
     assert max_abs(out["slot_history"].cpu(), hist) < 1e-4
     assert max_abs(out["pred_slots"].cpu(), preds) < 1e-4
     assert max_abs(out["pred_imgs"].cpu(), imgs) < 1e-4
-    assert_same_slot_assignment(out["masks"], masks.argmax(dim=1))
+    assert_same_slot_assignment(out["masks"], masks.argmax(dim=1), "e2e fresh inputs vs oracle (K=7, B=3)")
 
 
 @torch.no_grad()
@@ -358,6 +386,88 @@ def test_full_size_properties(k30):
     nodec = savi(mode="decomp", x=videos[:1], num_imgs=3, decode=False, init_noise=noise[:1])
     assert nodec["recons_imgs"].shape == (0, 3)
     assert max_abs(nodec["slot_history"].cpu(), dec["slot_history"].cpu()) == 0.0
+
+
+@torch.no_grad()
+def test_bench_shape_b128_against_b1_runs_and_oracle(k30):
+    """
+    The MEASURED shape (bench.py: B = 128, K = 30, 1 seed + 19 preds): the encoder runs in 3 chunks of <= 1024
+    images, the decoder in 36 chunks of 2040 slot images, slot attention splits every sample over 2 workgroups, the
+    GEMMs see their largest M (38400 rows).  None of the B <= 4 tests crosses those boundaries.
+      * samples 0, 63 and 127 of the batch equal their own batch-of-1 runs (<= 2e-5: GEMM tile shapes differ
+        with M, every per-sample kernel is batch-invariant);
+      * sample 0 equals the CPU oracle (<= 1e-4, the north-star bar) incl. the slot-index map of every frame.
+    """
+    savi, pred = k30
+    B, P = 128, 19
+    videos = gpu(synth.synth_videos(B, 1 + P, seed=61))
+    tokens, lengths = synth.synth_captions(B, max_len=12, seed=61)
+    noise = synth.synth_noise(B, 30, 128, seed=62)
+    out = forward_eval(savi, pred, videos, 1, P, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                       init_noise=noise, overlap_decode=False)
+    assert out["pred_imgs"].shape == (B, P, 3, 64, 64) and out["masks"].shape == (B * P, 30, 1, 64, 64)
+    assert torch.isfinite(out["pred_slots"]).all() and torch.isfinite(out["pred_imgs"]).all()
+    worst = {}
+    for b in (0, 63, 127):
+        one = forward_eval(savi, pred, videos[b:b + 1], 1, P, caption_tokens=gpu(tokens[b:b + 1]),
+                           caption_lengths=gpu(lengths[b:b + 1]), init_noise=noise[b:b + 1])
+        errs = {"slot_history": max_abs(one["slot_history"].cpu(), out["slot_history"][b:b + 1].cpu()),
+                "pred_slots": max_abs(one["pred_slots"].cpu(), out["pred_slots"][b:b + 1].cpu()),
+                "pred_imgs": max_abs(one["pred_imgs"].cpu(), out["pred_imgs"][b:b + 1].cpu()),
+                "masks": max_abs(one["masks"].cpu(), out["masks"][b * P:(b + 1) * P].cpu())}
+        print(f"B=128 sample {b} vs its B=1 run:", {k_: f"{v:.2e}" for k_, v in errs.items()})
+        for k_, v in errs.items():
+            worst[k_] = max(worst.get(k_, 0.0), v)
+    assert all(v <= 2e-5 for v in worst.values()), worst
+    ssd = {k_: v.cpu() for k_, v in savi.state_dict().items()}
+    psd = {k_: v.cpu() for k_, v in pred.state_dict().items()}
+    hist, preds, imgs, masks = O.forward_eval(ssd, psd, videos[:1].cpu(), tokens[:1], lengths[:1], noise[:1], 1, P)
+    errs = {"slot_history": max_abs(out["slot_history"][:1].cpu(), hist),
+            "pred_slots": max_abs(out["pred_slots"][:1].cpu(), preds),
+            "pred_imgs": max_abs(out["pred_imgs"][:1].cpu(), imgs),
+            "masks": max_abs(out["masks"][:P].cpu(), masks)}
+    print("B=128 sample 0 vs CPU oracle:", {k_: f"{v:.2e}" for k_, v in errs.items()})
+    assert all(v < 1e-4 for v in errs.values()), errs
+    assert_same_slot_assignment(out["masks"][:P], masks.argmax(dim=1), "B=128 sample 0 vs oracle (K=30, 19 frames)")
+    # overlapped decode (second stream) at this size: bit-identical to the serial order
+    ov = forward_eval(savi, pred, videos, 1, P, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                      init_noise=noise, overlap_decode=True)
+    assert torch.equal(ov["pred_imgs"], out["pred_imgs"]) and torch.equal(ov["pred_slots"], out["pred_slots"])
+
+
+@pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32", reason="the whole suite already runs in that mode")
+@torch.no_grad()
+def test_fp32_mode_in_process_slot_assignment_is_exact(monkeypatch):
+    """
+    The all-fp32 arithmetic (TOCVP_PRECISION=fp32: every GEMM / conv / attention product on the exact fp32 MFMA;
+    the slot-attention iteration keeps its split-fp16 contraction) selected IN THIS PROCESS before the models are
+    built: the reference goldens hold at the bar and the slot-index maps are identical -- no ties allowed.
+    """
+    from textocvp_amd import kernels as K
+    monkeypatch.setenv("TOCVP_PRECISION", "fp32")
+    monkeypatch.setattr(K, "_ATTN_QK16", False)
+    savi, pred = build(7, 4)
+    assert savi.decoder.conv_precision == "fp32" and pred.predictor.gemm_precision == "fp32"
+    g = load_golden("e2e_c1.npz")
+    videos = synth.synth_videos(2, 5, seed=0)
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    out = forward_eval(savi, pred, gpu(videos), 1, 4, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                       init_noise=noise)
+    assert max_abs(out["slot_history"].cpu(), g["slot_history"]) < 1e-4
+    assert max_abs(out["pred_slots"].cpu(), g["pred_slots"]) < 1e-4
+    assert max_abs(out["pred_imgs"].cpu(), g["pred_imgs"]) < 1e-4
+    assert_same_slot_assignment(out["masks"], g["masks_argmax"], "e2e config 1 (e2e_c1), fp32 mode in-process")
+    savi30, pred30 = build(30, 19, savi_family="undamped")
+    g30 = load_golden("parity_k30.npz")
+    videos = synth.synth_videos(1, 20, seed=0)
+    tokens, lengths = synth.synth_captions(1, max_len=12, seed=0)
+    noise = synth.synth_noise(1, 30, 128, seed=1)
+    e2e = forward_eval(savi30, pred30, gpu(videos), 1, 19, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                       init_noise=noise)
+    assert max_abs(e2e["recons_imgs"].cpu(), g30["undamped_c2_recons_imgs"]) < 1e-4
+    assert_same_slot_assignment(e2e["masks"], g30["undamped_c2_masks_argmax"],
+                                "e2e config 2, undamped family (parity_k30), fp32 mode in-process")
 
 
 @torch.no_grad()

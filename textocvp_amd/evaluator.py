@@ -4,6 +4,8 @@ Rollout evaluation harness: this repo's counterpart of the reference's ``Evaluat
 (:142-145, :168-171), re-designed for one process per GPU.
 
   * ``forward_eval``  -- the three module calls + reshape + clamp, identical glue to the reference.
+  * ``forward_eval_decomp`` -- the decomposition-only evaluation (03_evaluate_decomp_model.py:22-46):
+    ``model(x, num_imgs)`` with the default ``mode`` / ``decode=True``, clamp, metric tracker.
   * ``shard_batches`` -- whole reference batches are dealt round-robin to ranks (batch j -> rank
     j mod W): caption padding is per batch and leaks into predictions, so only
     batch-preserving sharding reproduces single-process results.
@@ -16,7 +18,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["forward_eval", "psnr_per_frame", "shard_batches", "gather_metrics"]
+__all__ = ["forward_eval", "forward_eval_decomp", "psnr_per_frame", "shard_batches", "gather_metrics"]
 
 
 _SIDE_STREAMS = {}
@@ -100,6 +102,29 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     # recons / recons_imgs: SAVi.decode's per-slot and composited frames, (B*P, ...) and UNclamped
     return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,
             "targets": targets, "masks": masks, "recons": recons, "recons_imgs": recons_imgs}
+
+
+@torch.no_grad()
+def forward_eval_decomp(decomp_model, videos, metric_tracker=None, **others):
+    """
+    Decomposition-only evaluation, the glue of the reference's ``Evaluator.forward_eval`` in
+    03_evaluate_decomp_model.py:22-46: every frame of ``videos`` (B, L, C, H, W) is decomposed AND
+    rendered (``mode`` and ``decode`` keep their defaults "decomp" / True, ``num_imgs = L``), the
+    reconstruction is clamped to [0, 1] and, if a tracker is given, accumulated against the raw
+    ``videos`` (:34-44).  ``others`` is what ``unwrap_batch_data`` yields (captions etc.: ignored by the
+    decomposition model) plus, optionally, ``init_noise``.
+    Returns the model's dictionary (recons_objs (B, L, K, C, H, W), masks (B, L, K, 1, H, W),
+    slot_history (B, L, K, D), recons_imgs UNclamped) with the clamped frames under "recons_clamped".
+    """
+    if videos.dim() != 5:
+        raise ValueError(f"videos with {videos.shape = }, but it must be (B, L, C, H, W)")
+    out_model = decomp_model(x=videos, num_imgs=videos.shape[1], **others)
+    recons_imgs = out_model.get("recons_imgs").clamp(0, 1)
+    if metric_tracker is not None:
+        metric_tracker.accumulate(preds=recons_imgs, targets=videos.to(recons_imgs.device))
+    out = dict(out_model)
+    out["recons_clamped"] = recons_imgs
+    return out
 
 
 def psnr_per_frame(preds, targets, eps=1e-8):

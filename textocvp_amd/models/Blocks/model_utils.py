@@ -6,7 +6,8 @@ Reference counterpart: models/Blocks/model_utils.py:66-79 (init_xavier_).
 import torch
 import torch.nn as nn
 
-__all__ = ["init_xavier_", "Derived", "require_inference", "RangeGuard"]
+__all__ = ["init_xavier_", "Derived", "require_inference", "RangeGuard", "refuse_replication", "freeze_params",
+           "unfreeze_params", "count_model_params"]
 
 
 @torch.no_grad()
@@ -17,6 +18,45 @@ def init_xavier_(model: nn.Module):
             p.zero_()
         elif p.dim() > 1:
             nn.init.xavier_uniform_(p)
+
+
+def freeze_params(model):
+    """ requires_grad = False on every parameter (model_utils.py:47-53) """
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+def unfreeze_params(model):
+    """ requires_grad = True on every parameter (model_utils.py:56-62) """
+    for p in model.parameters():
+        p.requires_grad = True
+    return model
+
+
+def count_model_params(model, verbose=False):
+    """ number of trainable parameters (model_utils.py:37-44) """
+    n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    if verbose:
+        print(f"Model has {n} trainable parameters")
+    return n
+
+
+def refuse_replication(self):
+    """
+    ``_replicate_for_data_parallel`` of the top-level mirrors.  The reference wraps its models in
+    ``nn.DataParallel(model, device_ids=range(num_gpus))`` (base/baseEvaluator.py:142-145, :168-171); with
+    ONE device that wrapper calls the module directly and works here unchanged.  With several devices
+    ``DataParallel.replicate`` would shallow-copy the module per forward: the replicas would share the
+    derived-weight caches (``Derived``), the caption K/V cache and the slot-attention workspace of device 0
+    -- raw pointers handed to kernels running on other devices.  This path is one process per GPU instead
+    (``evaluator.shard_batches`` / ``gather_metrics``, ``bench.py --gpus N``), so replication is refused loudly.
+    """
+    raise RuntimeError(
+        f"{type(self).__name__}: textocvp_amd modules cannot be replicated by nn.DataParallel over several "
+        f"devices (derived-weight caches and kernel workspaces are per device). Run one process per visible "
+        f"GPU -- torchrun / `bench.py --gpus N` with textocvp_amd.evaluator.shard_batches + gather_metrics -- "
+        f"or restrict the wrapper to one device (device_ids=[torch.cuda.current_device()]).")
 
 
 class Derived:

@@ -1,15 +1,18 @@
 """
 Transformer text encoder of TextOCVP_CustomTF.
 Reference: models/EncodersDecoders/text_encoders.py:14-138 (forward :89-125).
-The tokenizer (nltk based, :142-194) is data-side and out of scope.
+``CustomTokenizer`` (:142-194) is data-side host logic; a small counterpart is kept here only so that the
+reference's ``data/*.py`` imports resolve through the ``dropin/models`` alias package.
 """
+
+import re
 
 import torch
 import torch.nn as nn
 
 from ... import kernels as K
 
-__all__ = ["TransformerTextEncoder"]
+__all__ = ["TransformerTextEncoder", "CustomTokenizer"]
 
 
 class TransformerTextEncoder(nn.Module):
@@ -75,3 +78,41 @@ class TransformerTextEncoder(nn.Module):
                              layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         ln, proj = self.text_out_projection[0], self.text_out_projection[1]
         return K.linear(K.layer_norm(x, ln.weight, ln.bias, ln.eps), proj.weight, proj.bias)
+
+
+class CustomTokenizer:
+    """
+    Word-level caption tokenizer with the reference's surface (text_encoders.py:142-194): ``[CLS]`` + word
+    ids + ``[SEP]``, batches right-padded with ``[PAD]``.  Host-side integer bookkeeping (no kernel).  Words are
+    split with ``nltk.word_tokenize`` when nltk is installed (as in the reference), else on word / punctuation
+    boundaries -- identical on the CATER / CLIPort caption grammars (lower-case words, commas, full stops).
+    """
+
+    def __init__(self, vocabulary):
+        assert "[PAD]" in vocabulary, "Vocabulary must contain '[PAD]' token..."
+        self.padding_idx = vocabulary["[PAD]"]
+        self.vocabulary = vocabulary
+        self.vocabulary_reverse = {v: k for k, v in vocabulary.items()}
+
+    @staticmethod
+    def _words(text):
+        try:
+            import nltk
+            return nltk.word_tokenize(text)
+        except Exception:                                   # nltk (or its punkt data) absent
+            return re.findall(r"\w+|[^\w\s]", text)
+
+    def text2tokens(self, x):
+        return [self.vocabulary[w] for w in self._words(x)]
+
+    def tokenize(self, caption):
+        ids = [self.vocabulary["[CLS]"]] + self.text2tokens(caption) + [self.vocabulary["[SEP]"]]
+        return torch.tensor(ids, dtype=torch.long), torch.tensor(len(ids), dtype=torch.long)
+
+    def tokenize_batch(self, caption):
+        toks, lens = zip(*(self.tokenize(c) for c in caption))
+        toks = torch.nn.utils.rnn.pad_sequence(list(toks), batch_first=True, padding_value=self.padding_idx)
+        return toks, torch.stack(lens)
+
+    def tokens2text(self, tokens):
+        return "".join(" " + self.vocabulary_reverse[int(t)] for t in tokens)

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import kernels as K
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
-from .Blocks.model_utils import RangeGuard, init_xavier_, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 from .EncodersDecoders.encoders import get_encoder
@@ -27,6 +27,8 @@ __all__ = ["ExtendedDINOSAUR"]
 
 
 class ExtendedDINOSAUR(nn.Module, RangeGuard):
+    _replicate_for_data_parallel = refuse_replication      # one process per GPU, never DataParallel replicas
+
     def __init__(self, img_size, num_slots, slot_dim, num_iterations=1, num_iterations_first=3,
                  in_channels=3, mlp_hidden=128, mlp_encoder_dim=128, initializer=None, encoder=None,
                  decoder=None, transition_module=None, **kwargs):

@@ -5,12 +5,13 @@ Autoregressive rollout wrapper.  Reference: models/Predictors/predictor_wrapper.
 import torch
 import torch.nn as nn
 
-from ..Blocks.model_utils import RangeGuard
+from ..Blocks.model_utils import RangeGuard, refuse_replication
 
 __all__ = ["PredictorWrapper"]
 
 
 class PredictorWrapper(nn.Module, RangeGuard):
+
     """
     Rolls a predictor out for ``num_preds`` steps over a sliding window of at most
     ``input_buffer_size`` frames, conditioned on the encoded caption (reference forward :50-87).
@@ -23,6 +24,8 @@ class PredictorWrapper(nn.Module, RangeGuard):
     Host-side logic only: the window bookkeeping is slicing/concatenation of tiny (B, w, K, D)
     tensors; all arithmetic happens inside ``self.predictor`` on the HIP kernels.
     """
+
+    _replicate_for_data_parallel = refuse_replication      # one process per GPU, never DataParallel replicas
 
     def __init__(self, exp_params, predictor):
         super().__init__()

@@ -63,14 +63,29 @@ class BaseTextOCVP(nn.Module):
     def _instantiate_text_encoder(self):
         raise NotImplementedError("'BaseTextOCVP' does not implement '_instantiate_text_encoder'...")
 
+    def _text_kv_sources(self):
+        """ every parameter the cached caption K/V depend on: LayerNorm(text) and the k / v projections per layer """
+        src = []
+        for blk in self.predictor:
+            ca = blk.cross_attention
+            src += [ca.ln_cross_att_kv.weight, ca.ln_cross_att_kv.bias, ca.cross_attn.k.weight, ca.cross_attn.v.weight]
+        return src
+
     def prepare_text(self, text_embeddings):
-        """ per-layer fused cross-attention K/V of the caption (cached on tensor identity) """
+        """
+        per-layer fused cross-attention K/V of the caption.  Cached on the identity + version of the text
+        tensor AND on the (data_ptr, version, device) of every weight that enters them, plus the GEMM
+        arithmetic: ``load_state_dict`` / ``.to()`` / an optimiser step / a precision fallback between two calls
+        with the same text tensor rebuild the cache instead of serving stale K/V.
+        """
+        sig = (text_embeddings._version, text_embeddings.data_ptr(), self.gemm_precision,
+               tuple((t.data_ptr(), t._version, t.device.index) for t in self._text_kv_sources()))
         c = self._text_cache
-        if c is not None and c[0] is text_embeddings and c[1] == text_embeddings._version:
+        if c is not None and c[0] is text_embeddings and c[1] == sig:
             return c[2]
         with K.gemm_precision(self.gemm_precision, owner=(self, "gemm_precision")):
             kv = [blk.cross_attention.project_text(text_embeddings) for blk in self.predictor]
-        self._text_cache = (text_embeddings, text_embeddings._version, kv)
+        self._text_cache = (text_embeddings, sig, kv)
         return kv
 
     def forward(self, slots, text_embeddings, **kwargs):

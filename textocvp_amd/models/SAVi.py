@@ -15,7 +15,7 @@ from ..precision import knob
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
 from .Blocks.model_blocks import SoftPositionEmbed
-from .Blocks.model_utils import RangeGuard, init_xavier_, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 from .EncodersDecoders.encoders import get_encoder
@@ -35,6 +35,8 @@ class SAVi(nn.Module, RangeGuard):
         over frames (time-major chunks), only the slot recurrence stays sequential;
       * the decoder never materialises the (B*K, D, H, W) broadcast (see ConvDecoder).
     """
+
+    _replicate_for_data_parallel = refuse_replication      # one process per GPU, never DataParallel replicas
 
     def __init__(self, num_slots, slot_dim, num_iterations=1, num_iterations_first=3,
                  in_channels=3, mlp_hidden=128, mlp_encoder_dim=128,

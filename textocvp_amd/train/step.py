@@ -173,12 +173,13 @@ class PredictorTrainStep:
             out.append(v)
         return out
 
-    def all_reduce_grads(self):
-        """ average the gradients over the ranks with one all-reduce of a flat buffer """
+    def all_reduce_grads(self, force=False):
+        """ average the gradients over the ranks with one all-reduce of a flat buffer (``force``: also with a
+        single rank, where it is the identity -- exercises the collective itself on a one-GPU box) """
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
+        if world == 1 and not force:
             return
         vs = self._grads()
         flat = torch.cat([v.grad.reshape(-1) for v in vs])
