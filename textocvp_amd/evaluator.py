@@ -39,7 +39,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     (and optionally init_noise).  Returns dict(slot_history, pred_slots, pred_imgs, targets, masks,
     recons, recons_imgs).
 
-    overlap_decode (default: env TOCVP_OVERLAP_DECODE = auto|1|0; auto = on below 96 sequences): frame t is decoded on a SECOND HIP stream
+    overlap_decode (default on; env TOCVP_OVERLAP_DECODE=0 turns it off): frame t is decoded on a SECOND HIP stream
     as soon as rollout step t is enqueued.  The rollout is a chain of short dependent kernels that
     cannot fill 256 CUs (especially while the window is short); the MFMA-bound decoder convolutions
     of already-predicted frames run in the gaps.  Same kernels, same arithmetic, same results.
@@ -61,13 +61,11 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
                              decode=False, **others)
     slot_history = out_model["slot_history"]
     if overlap_decode is None:
-        # "auto": only below ~96 sequences.  With more, the rollout's GEMMs fill the chip on their own and
-        # the overlap buys little (round 2 kernels at B=128: 3490 vs 3390-3450 frames/s, +2-3 %; B=64: +1.3 %)
-        # while every kernel's duration gets inflated by the sharing (the decoder conv reads 318 instead of
-        # 425-435 TFLOP/s in situ), which would blur the per-kernel roofline the bench reports.
-        # TOCVP_OVERLAP_DECODE=1 takes the extra throughput.
-        mode = os.environ.get("TOCVP_OVERLAP_DECODE", "auto")
-        overlap_decode = (B < 96) if mode == "auto" else mode != "0"
+        # on by default at every batch size: same kernels, same arithmetic, bit-identical results
+        # (tests: test_decode_overlap_is_bit_identical, test_bench_shape_b128_*).  Below ~96 sequences the rollout
+        # cannot fill the chip and the gain is large; at B=128 it is +2-3 %.
+        # TOCVP_OVERLAP_DECODE=0 runs the serial order (what bench.py's per-kernel attribution pass uses).
+        overlap_decode = os.environ.get("TOCVP_OVERLAP_DECODE", "1") != "0"
     if not (overlap_decode and slot_history.is_cuda):
         pred_slots = predictor(slot_history, **others)
         out_dec = decomp_model(mode="decode",

@@ -174,8 +174,9 @@ def _weight_grad_tn(tape, W, b, g, x2):
             "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
     # later (accumulating) uses with few rows touch only as many slices as they can keep busy
     active = ent["splits"] if first else max(1, min(ent["splits"], M // 128))
-    K._check(_L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
-                                    active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32")
+    K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
+        _L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
+                               active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32"))
 
 
 def _finish_weight_grad(ent):
