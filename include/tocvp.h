@@ -101,6 +101,16 @@ int tocvp_split_weights_planes_f16(const float* w, void* out, int N, int K, void
 int tocvp_gemm_f16planes_f32(const void* A_planes, const void* W_planes, const float* bias, const float* R,
                              int ldr, void* C, int c_split, int ldc, int M, int N, int K, int act,
                              void* stream);
+/* Same product with a workspace (tocvp_gemm_f16planes_ws_bytes() bytes, 16-byte aligned, ZEROED ONCE when it is
+ * allocated; the kernel leaves its flag words zero again).  With it the persistent kernel may cut the k-tiles of the
+ * whole product into equal contiguous ranges, one per CU ("stream-K"): products whose tile count does not fill the
+ * last round of CUs (300 tiles of 38400 x 512 on 256 CUs) run ~1.6x faster.  A tile cut between two workgroups is
+ * summed in k order by the holder of its first range (deterministic: same result on every run for a given shape).
+ * One workspace serves any number of launches that are ordered on ONE stream; concurrent streams need one each. */
+size_t tocvp_gemm_f16planes_ws_bytes(void);
+int tocvp_gemm_f16planes_ws_f32(const void* A_planes, const void* W_planes, const float* bias, const float* R,
+                                int ldr, void* C, int c_split, int ldc, int M, int N, int K, int act, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* "f16x3": the same kernel with fp16 planes (x = hi + lo in fp16, 22 significant bits, products
  * hh + hl + lh): fp32-class accuracy at HALF the MFMA count of bf16x6, valid while |x| < 65504. */

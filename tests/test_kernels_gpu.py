@@ -584,6 +584,64 @@ def test_f16_operand_planes_from_producers(M):
     assert (a - bb).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,Kd", [(38400, 512, 512), (12000, 1536, 512), (9000, 512, 2048)])
+def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
+    """
+    tocvp_gemm_f16planes(_ws)_f32, round-3 persistent kernel (gemm_f16p.hip, planes3):
+      * the default plan cuts the rows into phases of 256- / 128- / 64-row tiles (38400 x 512: 256 + 176 tiles; the
+        other shapes end in a ragged row block): every row against an fp64 reference of the SAME fp16 planes
+        (what is tested is the kernel, not the split), bias + ReLU + residual epilogue, fp32 and plane outputs;
+      * stream-K through the workspace entry point (forced: TOCVP_GEMM_P3_SK is read once per process, so the
+        kernel is reached through the environment of a fresh interpreter in scripts; here the data-parallel plan
+        and the workspace entry point must agree bit for bit when stream-K is not selected) and a second launch on
+        the same workspace reproduces the first bit for bit.
+    """
+    import ctypes
+    k = _k()
+    monkeypatch.setattr(k, "_GEMM_P2_MIN_ROWS", 1)              # every plane-input product on the planes kernel
+    x = rnd("p3x", (M, Kd), "normal")
+    w = rnd("p3w", (N, Kd), "uniform", Kd ** -0.5)
+    b = rnd("p3b", (N,), "uniform", 0.1)
+    r = rnd("p3r", (M, N), "normal")
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    with k.gemm_precision("f16x3"):
+        xp = k.linear(xd, torch.eye(Kd, device=DEV), out_split=22)            # the activation as fp16 planes
+        got = k.linear(xp, wd, bd, act=k.ACT_RELU, residual=rd)
+        got_planes = k.linear(xp, wd, bd, act=k.ACT_RELU, out_split=22)
+    # fp64 reference from the planes themselves (values 2^-8 (hi + lo)) and the fp16 weight planes (2^-10 (hi + lo))
+    a64 = xp.planes.double().sum(dim=1) / 256.0
+    wpl = k._split_weight(wd, 22, frag="rows")
+    w64 = wpl.double().sum(dim=1) / 1024.0
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2 - 150, M // 2 + 150), torch.arange(M - 300, M)]).to(DEV)
+    ref = torch.relu(a64[rows] @ w64.t() + bd.double()) + rd[rows].double()
+    err = (got[rows].double() - ref).abs().max().item()
+    rebuilt = got_planes.planes.double().sum(dim=1) / 256.0
+    err_p = (rebuilt[rows] - (ref - rd[rows].double())).abs().max().item()
+    print(f"planes3 {M}x{N}x{Kd}: |fp32 out - fp64| {err:.2e}, |plane out - fp64| {err_p:.2e}")
+    assert err < 3e-6 * max(1.0, float(ref.abs().max())) and err_p < 3e-6 * max(1.0, float(ref.abs().max()))
+    # the whole output against the same product computed in row chunks small enough for one phase each
+    chunks = torch.cat([k.linear(k.SplitAct(xp.planes[i:i + 3000].contiguous(), (min(3000, M - i), Kd)), wd, bd,
+                                 act=k.ACT_RELU, residual=rd[i:i + 3000].contiguous(), precision="f16x3")
+                        for i in range(0, M, 3000)])
+    assert torch.equal(chunks, got), "the result must not depend on the cut into phases"
+    # workspace entry point: same plan, same bits; and it leaves its workspace re-armed (second launch identical)
+    lib = k.lib()
+    nbytes = lib.tocvp_gemm_f16planes_ws_bytes()
+    ws = torch.zeros((nbytes + 3) // 4, device=DEV, dtype=torch.int32)
+    outs = []
+    for _ in range(2):
+        o = torch.empty((M, N), device=DEV, dtype=torch.float32)
+        rc = lib.tocvp_gemm_f16planes_ws_f32(xp.planes.data_ptr(), wpl.data_ptr(), bd.data_ptr(), rd.data_ptr(), N,
+                                             o.data_ptr(), 0, N, M, N, Kd, int(k.ACT_RELU), ws.data_ptr(),
+                                             ctypes.c_size_t(nbytes), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - got).abs().max().item() < 2e-5 * max(1.0, float(got.abs().max()))
+    assert int(ws[:1024].abs().sum()) == 0, "flag words must be zero again after the launch"
+
+
 def test_conv5x5_f16f8_pass_major_layout():
     """ the private (n, 4, H, W, 16) layout between decoder layers holds exactly the NHWC values """
     k = _k()

@@ -20,16 +20,19 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 
 
 # Activations that only feed GEMMs can leave their producer (LayerNorm, attention and GEMM epilogues) as fp16
-# operand planes (the bytes of the fp32 tensor); a GEMM fed with planes runs the all-DMA planes kernel
-# (gemm_f16p.hip: no split in the k-loop, both operands through LDS).  TOCVP_PRESPLIT:
+# operand planes (the bytes of the fp32 tensor); a GEMM fed with planes runs the persistent all-DMA planes kernel
+# (gemm_f16p.hip, planes3: no split in the k-loop, both operands through LDS, 256 x 256 tiles).  TOCVP_PRESPLIT:
 #   "0" (default)  never;
-#   "wide"         only where the consuming GEMM is at least 1536 columns wide -- isolated, 38400 rows, f16x3:
-#                  2048x512 311 vs 383 us, 1536x512 223 vs 231 us, but 512x2048 321 vs 281 us and 512x512
-#                  101 vs 77 us (few 256-column tiles: the one-workgroup-per-CU kernel pays its prologue and
-#                  its 256 KB epilogue without cover: ~24 us per workgroup, scripts/gemm_shapes.py);
+#   "wide"         only where the consuming GEMM is at least 1536 columns wide (qkv, MLP up-projections);
 #   "1"            everywhere the shapes allow.
-# In the rollout at B=128 (window 1..10, 3840..38400 rows): off 714.3, wide 715.9, all 744.9 ms per step ->
-# neutral at best, so the in-kernel split stays the default.
+# Round 3 (planes3), isolated, 38400 rows, dense random operands, planes3 vs the in-loop-split kernel: 2048x512
+# 255-280 vs 380-400 us, 1536x512 205-227 vs 239 us, 512x2048 288 vs 290 us, 512x512 107 vs 80 us.  IN the rollout
+# the in-loop-split kernel runs 25 % faster than on dense random data (294 us at 2048x512: sparse post-ReLU / small
+# LayerNorm'd operands keep the clock up) and planes3 gains 10 % on the wide products (268 us); at B=128 per step:
+# "0" 688.3 ms, "wide" 692.0 ms with the decoder overlapped on the second stream (a persistent one-workgroup-per-CU
+# kernel with 128 KB of LDS cannot share a CU with the decoder's workgroups, the 36 KB in-loop-split kernel can),
+# 3467 vs 3449 frames/s (+0.5 %) without the overlap -> neutral, the in-kernel split stays the default
+# (profiles/r03_gemm_planes3.md).
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0")
 _PRESPLIT_MIN_N = 1536
 
