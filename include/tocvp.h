@@ -383,6 +383,22 @@ size_t tocvp_metrics_ws_bytes(int N, int C);
 int tocvp_psnr_ssim_f32(const float* preds, const float* targets, float* psnr, float* ssim, int N,
                         int C, int H, int W, int clamp01, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Text cross-attention of one predictor block, collapsed over the caption (csrc/xattn.hip):
+ *     y = x + out_projection( softmax_t( (LayerNorm(x) Wq^T) K^T * scale ) V ) + bias
+ * with the query / output projections folded into per-sample caption operands built once per rollout:
+ *     G  (B * heads * 16, E): row (b, h, t) = sum_d Wq[h dh + d, :] K[b, t, h dh + d]   (zero rows for t >= Lt)
+ *     HT (B * E, heads * 16): row (b, c), column (h, t) = sum_d Wo[c, h dh + d] V[b, t, h dh + d]
+ * both as fp16 operand planes of 2^10 w in MFMA-fragment order (tocvp_split_weights_frag_f16 of the fp32 matrices).
+ * x, y (B, Tq, E) fp32 contiguous; E = 512, heads = 8, dh = 64, 1 <= Lt <= 16.  One launch replaces LayerNorm,
+ * nn.Linear q, MetaAttention.attention over the caption and out_projection (+ residual) of the reference's
+ * TransformerDecoderBlock.forward (models/Blocks/attention.py:445-463, 303-319); f16x3 arithmetic (fp32-class),
+ * LayerNorm and softmax in fp32.  Padded caption positions take part as in the reference (no key mask).
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, const float* beta, float eps, const void* Gfrag,
+                              const void* Hfrag, const float* bias, float* y, int B, int Tq, int E, int heads,
+                              int Lt, float scale, void* stream);
+
 /* =============================================================================================
  * Predictor TRAINING step (reference 04_train_predictor.py:57-108,
  * lib/loss.py:150-191, lib/setup_model.py:285-332): backward and optimiser kernels.  The forward

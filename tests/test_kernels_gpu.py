@@ -642,6 +642,61 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
     assert int(ws[:1024].abs().sum()) == 0, "flag words must be zero again after the launch"
 
 
+@pytest.mark.parametrize("B,Tq,Lt", [(3, 300, 12), (2, 37, 5), (1, 30, 16)])
+def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt):
+    """
+    csrc/xattn.hip: LayerNorm + q projection + attention over the caption + output projection + residual in ONE
+    kernel, with the projections folded into per-sample caption operands.  Against (a) an fp64 evaluation of the
+    reference's TransformerDecoderBlock cross-attention half (attention.py:445-463, 303-319) and (b) this repo's
+    four-kernel path on the same module (TextKV without collapsed operands); ragged Tq, Lt < 16 (masked slots).
+    """
+    from textocvp_amd.models.Blocks.attention import TextKV, TransformerDecoderBlock
+    k = _k()
+    E, H, dh = 512, 8, 64
+    blk = TransformerDecoderBlock(embed_dim=E, head_dim=dh, kv_dim=E, num_heads=H, mlp_size=2048).eval()
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if p_.dim() > 1:
+                p_.copy_(rnd("xa." + n_, tuple(p_.shape), "uniform", p_.shape[1] ** -0.5))
+            else:
+                p_.copy_((1.0 if "weight" in n_ else 0.0) + rnd("xa." + n_, tuple(p_.shape), "uniform", 0.2))
+    x = rnd("xa.x", (B, Tq, E), "normal") * 1.5
+    text = rnd("xa.text", (B, Lt, E), "normal")
+    # (a) fp64 reference of the cross-attention half: z = x + out_proj(softmax(q k^T / sqrt(dh)) v)
+    P64 = {n_: p_.detach().double() for n_, p_ in blk.named_parameters()}
+    ln = torch.nn.functional.layer_norm
+    qn = ln(x.double(), (E,), P64["ln_cross_att_q.weight"], P64["ln_cross_att_q.bias"], 1e-6)
+    tn = ln(text.double(), (E,), P64["ln_cross_att_kv.weight"], P64["ln_cross_att_kv.bias"], 1e-6)
+    q = (qn @ P64["cross_attn.q.weight"].t()).view(B, Tq, H, dh).transpose(1, 2)
+    kk = (tn @ P64["cross_attn.k.weight"].t()).view(B, Lt, H, dh).transpose(1, 2)
+    vv = (tn @ P64["cross_attn.v.weight"].t()).view(B, Lt, H, dh).transpose(1, 2)
+    att = torch.softmax(q @ kk.transpose(-1, -2) * dh ** -0.5, dim=-1) @ vv
+    z_ref = x.double() + att.transpose(1, 2).reshape(B, Tq, E) @ P64["cross_attn.out_projection.weight"].t() \
+        + P64["cross_attn.out_projection.bias"]
+    blk = blk.to(DEV)
+    xd, td = x.to(DEV), text.to(DEV)
+    with torch.no_grad(), k.gemm_precision("f16x3"):
+        tkv = blk.project_text(td)
+        assert isinstance(tkv, TextKV) and tkv.collapsed is not None and tkv.collapsed[2] == Lt
+        Gf, Hf, _ = tkv.collapsed
+        lnq = blk.ln_cross_att_q
+        z = k.xattn_collapsed(xd, lnq.weight, lnq.bias, lnq.eps, Gf, Hf, blk.cross_attn.out_projection.bias, H, Lt,
+                              dh ** -0.5)
+        z4 = blk.cross_attn(None, query_embs=k.layer_norm(xd, lnq.weight, lnq.bias, lnq.eps), residual=xd, kv=tkv.kv)
+        full = blk(xd, td, text_kv=tkv)                                    # fused path inside the block
+        full4 = blk(xd, td, text_kv=TextKV(tkv.kv, None))                  # four-kernel path
+    err = (z.cpu().double() - z_ref).abs().max().item()
+    err4 = (z4.cpu().double() - z_ref).abs().max().item()
+    print(f"collapsed cross-attention B={B} Tq={Tq} Lt={Lt}: |fused - fp64| {err:.2e}, |four kernels - fp64| {err4:.2e}, "
+          f"|block fused - block four| {(full - full4).abs().max().item():.2e}")
+    assert err < 5e-6 * max(1.0, float(z_ref.abs().max())) and err < 3 * err4 + 2e-6
+    assert (full - full4).abs().max().item() < 2e-5
+    assert torch.isfinite(z).all()
+    # captions longer than 16 tokens fall back to the four-kernel path
+    with torch.no_grad(), k.gemm_precision("f16x3"):
+        assert blk.project_text(rnd("xa.long", (B, 20, E), "normal").to(DEV)).collapsed is None
+
+
 def test_conv5x5_f16f8_pass_major_layout():
     """ the private (n, 4, H, W, 16) layout between decoder layers holds exactly the NHWC values """
     k = _k()

@@ -1,0 +1,219 @@
+// Text cross-attention of the predictor blocks, COLLAPSED over the caption (round 3).
+//
+// Replaces, per AdaptedEncoderBlock and rollout step (reference models/Blocks/attention.py:445-463, 303-319):
+//     z = x + out_projection( softmax_t( q K^T / sqrt(dh) ) V ) ,  q = LayerNorm(x) Wq^T
+// i.e. LayerNorm -> 512x512 GEMM -> attention over Lt caption tokens -> 512x512 GEMM (+ bias + residual): four
+// kernels, 2 x 2 x 512 x 512 FLOP per token.  Keys and values depend on the caption only, so both projections fold
+// into per-sample operands that are built ONCE per rollout (TransformerDecoderBlock.project_text):
+//     G_b[h, t, :]  = scale * sum_d Wq[h dh + d, :] K_b[t, h dh + d]         (H Lt x E)   scores  = LN(x) G_b^T
+//     HT_b[:, h, t] =         sum_d Wo[:, h dh + d] V_b[t, h dh + d]         (E x H Lt)   output  = P HT_b^T
+// -- the same numbers up to fp32 re-association, with H Lt = 8 x 12 columns instead of 512: 2 x 2 x 512 x 128 FLOP per
+// token (tokens per head padded to 16) and ONE kernel.  Padded caption positions take part as in the reference
+// (no key mask, attention.py:314); slots t >= Lt of a head are excluded from its softmax.
+//
+// One workgroup (4 waves) = 32 tokens of one sample:
+//   phase 0  LayerNorm of the 32 rows in registers (the arithmetic of layernorm_kernel, misc.hip), written as fp16
+//            operand planes (2^8 x = hi + lo) into LDS, rows padded to 2064 B (conflict-free ds_read_b128);
+//   phase 1  S^T = G_b LN(x)^T on the f16 matrix cores (three products per operand pair, fp32-class): wave w owns the
+//            32 score rows of heads 2w, 2w+1; G fragments come straight from L2 in MFMA-fragment order; with the
+//            caption slots on the accumulator ROWS the softmax over t is in-lane plus one cross-half exchange;
+//   phase 2  P goes back through LDS as operand planes (over the dead LN image), Y^T = HT_b P^T: wave w owns 128
+//            output columns; a lane holds four consecutive columns of one token per register quad, so bias,
+//            residual and the 16-byte stores come straight from the accumulators.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int E = 512, HEADS = 8, LP = 16, NP = HEADS * LP;          // 128 padded score columns
+constexpr int XROW = 2 * E * 2 + 16;                                 // LN image: [row][plane][k] + 16 B pad = 2064 B
+constexpr int PROW = 2 * NP * 2 + 16;                                // P image:  [row][plane][n] + 16 B pad = 528 B
+constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
+
+struct XArgs {
+    const float* x; const float* gamma; const float* beta; float eps;
+    const _Float16* Gf; const _Float16* Hf; const float* bias; float* y;
+    int B, Tq, Lt; float scale;
+};
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void xattn_collapsed_kernel(XArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[32 * XROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, r0 = blockIdx.x * 32;
+    const float* xb = p.x + (size_t)b * p.Tq * E;
+
+    // ---- phase 0: LayerNorm of rows 8 wave .. 8 wave + 7 (rows past Tq repeat the last row; never stored)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = wave * 8 + i;
+        const float* xr = xb + (size_t)min(r0 + rl, p.Tq - 1) * E;
+        f32x4 v[2];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u] = *reinterpret_cast<const f32x4*>(xr + (lane + 64 * u) * 4);
+            s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        }
+        const float mean = wave_sum64(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 d = v[u] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)E + p.eps);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = (lane + 64 * u) * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+            f32x4 o = (v[u] - mean) * rstd * g + be;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = __builtin_amdgcn_fmed3f(o[e] * SA, -65504.f, 65504.f);
+                hi[e] = (_Float16)sc;
+                lo[e] = (_Float16)(sc - (float)hi[e]);
+            }
+            *reinterpret_cast<f16x4*>(lds + rl * XROW + c * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + rl * XROW + E * 2 + c * 2) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: S^T tile of this wave: rows n = 32 wave + .. (heads 2 wave, 2 wave + 1), columns m = 32 tokens
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    {
+        const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + wave) * (E / 16) * 2) * 64 + lane;
+        const unsigned char* xl = lds + l31 * XROW + hh * 16;
+        f16x8 gh = gf[0], gl = gf[64];
+#pragma unroll 4
+        for (int ks = 0; ks < E / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + ks * 32);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(xl + E * 2 + ks * 32);
+            const f16x8 wh = gh, wl = gl;
+            if (ks + 1 < E / 16) {
+                gh = gf[(size_t)(ks + 1) * 128];
+                gl = gf[(size_t)(ks + 1) * 128 + 64];
+            }
+            sacc = mfma16(wh, al, sacc);
+            sacc = mfma16(wl, ah, sacc);
+            sacc = mfma16(wh, ah, sacc);
+        }
+    }
+    // softmax over the caption slots of each head: register r of lane half hh = slot t = 4 hh + (r & 3) + 8 ((r >> 2) & 1)
+    // of head 2 wave + (r >> 3); the other half of the slots sits in lane ^ 32
+    float pr[16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+            const float sv = sacc[8 * g + q] * p.scale;
+            pr[8 * g + q] = sv;
+            if (tt < p.Lt) mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+            const float e = tt < p.Lt ? expf(pr[8 * g + q] - mx) : 0.f;
+            pr[8 * g + q] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pr[8 * g + q] *= inv;
+    }
+    __syncthreads();                                  // every wave has finished reading the LN image
+    // P as operand planes: row m = l31, column n = 32 wave + 16 g + 8 u + 4 hh + {0..3}
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = pr[8 * g + 4 * u + e] * SA;
+                hi[e] = (_Float16)sc;
+                lo[e] = (_Float16)(sc - (float)hi[e]);
+            }
+            const int n = 32 * wave + 16 * g + 8 * u + 4 * hh;
+            *reinterpret_cast<f16x4*>(lds + l31 * PROW + n * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + l31 * PROW + NP * 2 + n * 2) = lo;
+        }
+    __syncthreads();
+
+    // ---- phase 2: Y^T tiles of this wave: rows c = 128 wave + 32 j + .., columns m
+    f32x16 yacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[j][r] = 0.f;
+    {
+        const unsigned char* pl = lds + l31 * PROW + hh * 16;
+#pragma unroll
+        for (int ks = 0; ks < NP / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(pl + ks * 32);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(pl + NP * 2 + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x8* hf = reinterpret_cast<const f16x8*>(p.Hf) +
+                                  (((size_t)(b * (E / 32) + wave * 4 + j) * (NP / 16) + ks) * 2) * 64 + lane;
+                const f16x8 wh = hf[0], wl = hf[64];
+                yacc[j] = mfma16(wh, al, yacc[j]);
+                yacc[j] = mfma16(wl, ah, yacc[j]);
+                yacc[j] = mfma16(wh, ah, yacc[j]);
+            }
+        }
+    }
+    // ---- epilogue: register quad q of tile j = columns 128 wave + 32 j + 8 q + 4 hh .. + 3 of token r0 + l31
+    const int row = r0 + l31;
+    if (row < p.Tq) {
+        const float* xr = xb + (size_t)row * E;
+        float* yr = p.y + ((size_t)b * p.Tq + row) * E;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 128 * wave + 32 * j + 8 * q + 4 * hh;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + c);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = yacc[j][4 * q + e] * (1.f / (SA * SW)) + bv[e] + rv[e];
+                *reinterpret_cast<f32x4*>(yr + c) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, const float* beta, float eps,
+                                         const void* Gfrag, const void* Hfrag, const float* bias, float* y, int B,
+                                         int Tq, int E_, int heads, int Lt, float scale, void* stream) {
+    TOCVP_CHECK_ARG(x && gamma && beta && Gfrag && Hfrag && bias && y);
+    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= LP);
+    TOCVP_CHECK_ARG(B <= 65535);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) || !tocvp_aligned16(beta) ||
+        !tocvp_aligned16(bias) || !tocvp_aligned16(Gfrag) || !tocvp_aligned16(Hfrag))
+        return TOCVP_EALIGN;
+    if (B == 0 || Tq == 0) return TOCVP_OK;
+    XArgs p{x, gamma, beta, eps, static_cast<const _Float16*>(Gfrag), static_cast<const _Float16*>(Hfrag), bias, y,
+            B, Tq, Lt, scale * (1.f / (SA * SW))};
+    hipLaunchKernelGGL(xattn_collapsed_kernel, dim3((Tq + 31) / 32, B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return tocvp_launch_status();
+}

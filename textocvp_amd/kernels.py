@@ -60,6 +60,10 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_xattn_collapsed_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_float, ctypes.c_void_p]),
     "tocvp_layernorm_split_bf16": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
@@ -584,6 +588,43 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
                                      _ptr(y), rows, D, float(eps), _stream()),
            "tocvp_layernorm_f32")
     return y.reshape(x.shape)
+
+
+def xattn_operands(G, HT):
+    """
+    G (B * 128, 512), HT (B * 512, 128) fp32 -> their fp16 operand planes (2^10 w = hi + lo) in MFMA-fragment
+    order, as tocvp_xattn_collapsed_f32 reads them.  Checked mode verifies |w| < 63 like every fp16-plane weight.
+    """
+    _dev_f32(G, "G"), _dev_f32(HT, "HT")
+    outs = []
+    for w in (G, HT):
+        assert w.is_contiguous()
+        if _CHECK_RANGE:
+            _check_f16_weight_range(w, "collapsed cross-attention operand")
+        N, Kd = w.shape
+        out = torch.empty((N, 2, Kd), device=w.device, dtype=torch.float16)
+        _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, Kd, _stream()), "tocvp_split_weights_frag_f16")
+        outs.append(out)
+    return tuple(outs)
+
+
+def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
+    """
+    z = x + CrossAttention(LayerNorm(x), caption) with the projections folded into the caption operands
+    (csrc/xattn.hip): x (B, Tq, 512) fp32 contiguous -> (B, Tq, 512).
+    """
+    _dev_f32(x, "x")
+    B, Tq, E = x.shape
+    assert x.is_contiguous() and Gf.shape[0] == B * heads * 16 and Hf.shape[0] == B * E
+    if _CHECK_RANGE:                               # |LayerNorm(x)| <= sqrt(E) max|gamma| + max|beta|
+        _check_f16_range(float(gamma.abs().max()) * E ** 0.5 + float(beta.abs().max()),
+                         "collapsed cross-attention: bound of the LayerNorm output")
+    y = torch.empty_like(x)
+    _timed(f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * 16, lambda: _check(
+        lib().tocvp_xattn_collapsed_f32(_ptr(x), _ptr(gamma), _ptr(beta), float(eps), _ptr(Gf), _ptr(Hf), _ptr(bias),
+                                        _ptr(y), B, Tq, E, int(heads), int(Lt), float(scale), _stream()),
+        "tocvp_xattn_collapsed_f32"))
+    return y
 
 
 # matrix products of the attention kernel (Q K^T and P V): "f16x3" (split fp16 operands on the f16 matrix

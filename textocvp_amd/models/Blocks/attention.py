@@ -35,6 +35,19 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # (profiles/r03_gemm_planes3.md).
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0")
 _PRESPLIT_MIN_N = 1536
+# text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
+# LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
+_XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
+
+
+class TextKV:
+    """ step-invariant caption operands of one predictor block: the fused [k | v] projection (B, Lt, 2 inner) and,
+    for captions of at most 16 tokens, the collapsed operands (G fragments, HT fragments, Lt) of csrc/xattn.hip """
+
+    __slots__ = ("kv", "collapsed")
+
+    def __init__(self, kv, collapsed=None):
+        self.kv, self.collapsed = kv, collapsed
 
 
 def _ln(x, ln, add=None, split=0):
@@ -259,6 +272,34 @@ class MultiHeadCrossAttention(MetaAttention):
                               lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
         return K.linear(enc_embs, w)
 
+    def collapse(self, kv):
+        """
+        Fold the query and output projections into per-sample operands of the caption (csrc/xattn.hip):
+            G[b, h, t, :]  = sum_d Wq[h dh + d, :] K[b, t, h dh + d]      scores = LN(x) G^T (x dim_head ** -0.5)
+            HT[b, :, h, t] = sum_d Wo[:, h dh + d] V[b, t, h dh + d]      output = P HT^T
+        as fp16 operand planes in MFMA-fragment order, caption slots of a head padded to 16.  Built once per
+        caption batch; exact up to fp32 re-association.  None when the shapes do not fit the fused kernel
+        (more than 16 caption tokens, other widths) -- the caller then takes the four-kernel path.
+        """
+        B, Lt, two_inner = kv.shape
+        H, dh, inner = self.num_heads, self.dim_head, two_inner // 2
+        E_in, E_out = self.q.weight.shape[1], self.out_projection.weight.shape[0]
+        if not (_XATTN_COLLAPSE and Lt <= 16 and H == 8 and dh == 64 and E_in == 512 and E_out == 512 and
+                self.out_projection.bias is not None and K.active_nsplit() == 22):
+            return None
+        wq_t = self._derived.get("wq_heads", [self.q.weight], lambda: [
+            self.q.weight[h * dh:(h + 1) * dh, :].t().contiguous() for h in range(H)])          # (E_in, dh) each
+        wo_h = self._derived.get("wo_heads", [self.out_projection.weight], lambda: [
+            self.out_projection.weight[:, h * dh:(h + 1) * dh].contiguous() for h in range(H)])  # (E_out, dh) each
+        G = torch.zeros((B, H, 16, E_in), device=kv.device, dtype=torch.float32)
+        HT = torch.zeros((B, E_out, H, 16), device=kv.device, dtype=torch.float32)
+        for h in range(H):
+            kh = kv[:, :, h * dh:(h + 1) * dh].reshape(B * Lt, dh).contiguous()
+            vh = kv[:, :, inner + h * dh:inner + (h + 1) * dh].reshape(B * Lt, dh).contiguous()
+            G[:, h, :Lt] = K.linear(kh, wq_t[h]).view(B, Lt, E_in)                     # data movement into the pad
+            HT[:, :, h, :Lt] = K.linear(vh, wo_h[h]).view(B, Lt, E_out).transpose(1, 2)
+        return K.xattn_operands(G.view(B * H * 16, E_in), HT.view(B * E_out, H * 16)) + (Lt,)
+
     def forward(self, enc_embs, query_embs, residual=None, kv=None, **kwargs):
         if kv is None:
             kv = self.project_kv(enc_embs)
@@ -315,13 +356,25 @@ class TransformerDecoderBlock(nn.Module):
             emb_dim=embed_dim, dim_head=head_dim, num_heads=num_heads, kv_dim=kv_dim)
 
     def project_text(self, feats):
-        """ step-invariant half of the block: LayerNorm(text) -> fused K/V projection """
-        return self.cross_attn.project_kv(_ln(feats.contiguous(), self.ln_cross_att_kv))
+        """ step-invariant half of the block: LayerNorm(text) -> fused K/V projection (+ the collapsed operands of
+        the fused cross-attention kernel when the caption is short enough) """
+        kv = self.cross_attn.project_kv(_ln(feats.contiguous(), self.ln_cross_att_kv))
+        return TextKV(kv, self.cross_attn.collapse(kv))
 
     def forward(self, queries, feats, text_kv=None):
         assert queries.ndim == 3
         if text_kv is None:
             text_kv = self.project_text(feats)
+        if isinstance(text_kv, TextKV):
+            if text_kv.collapsed is not None and K.active_nsplit() == 22 and not isinstance(queries, K.SplitAct):
+                # LayerNorm + query projection + attention over the caption + output projection + residual: ONE kernel
+                Gf, Hf, Lt = text_kv.collapsed
+                lnq = self.ln_cross_att_q
+                z = K.xattn_collapsed(queries, lnq.weight, lnq.bias, lnq.eps, Gf, Hf, self.cross_attn.out_projection.bias,
+                                      self.cross_attn.num_heads, Lt, self.cross_attn.dim_head ** -0.5)
+                return _mlp(_ln(z, self.ln_mlp, split=_ns(queries.shape[-1], self.mlp[0].weight.shape[0],
+                                                          n_out=self.mlp[0].weight.shape[0])), self.mlp, residual=z)
+            text_kv = text_kv.kv
         E = queries.shape[-1]
         z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q,
                                                  split=_ns(E, n_out=self.cross_attn.q.weight.shape[0])),

@@ -68,7 +68,8 @@ class BaseTextOCVP(nn.Module):
         src = []
         for blk in self.predictor:
             ca = blk.cross_attention
-            src += [ca.ln_cross_att_kv.weight, ca.ln_cross_att_kv.bias, ca.cross_attn.k.weight, ca.cross_attn.v.weight]
+            src += [ca.ln_cross_att_kv.weight, ca.ln_cross_att_kv.bias, ca.cross_attn.k.weight, ca.cross_attn.v.weight,
+                    ca.cross_attn.q.weight, ca.cross_attn.out_projection.weight]      # collapsed operands (xattn.hip)
         return src
 
     def prepare_text(self, text_embeddings):
