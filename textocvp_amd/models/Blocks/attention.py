@@ -291,13 +291,17 @@ class MultiHeadCrossAttention(MetaAttention):
             self.q.weight[h * dh:(h + 1) * dh, :].t().contiguous() for h in range(H)])          # (E_in, dh) each
         wo_h = self._derived.get("wo_heads", [self.out_projection.weight], lambda: [
             self.out_projection.weight[:, h * dh:(h + 1) * dh].contiguous() for h in range(H)])  # (E_out, dh) each
+        # per head one small GEMM each into contiguous slabs, then ONE strided copy per operand into the padded layout
+        g_heads = torch.empty((H, B * Lt, E_in), device=kv.device, dtype=torch.float32)
+        h_heads = torch.empty((H, B * Lt, E_out), device=kv.device, dtype=torch.float32)
+        kv_h = kv.view(B, Lt, 2, H, dh).permute(2, 3, 0, 1, 4).contiguous().view(2, H, B * Lt, dh)   # one copy
+        for h in range(H):
+            K.linear(kv_h[0, h], wq_t[h], out=g_heads[h])
+            K.linear(kv_h[1, h], wo_h[h], out=h_heads[h])
         G = torch.zeros((B, H, 16, E_in), device=kv.device, dtype=torch.float32)
         HT = torch.zeros((B, E_out, H, 16), device=kv.device, dtype=torch.float32)
-        for h in range(H):
-            kh = kv[:, :, h * dh:(h + 1) * dh].reshape(B * Lt, dh).contiguous()
-            vh = kv[:, :, inner + h * dh:inner + (h + 1) * dh].reshape(B * Lt, dh).contiguous()
-            G[:, h, :Lt] = K.linear(kh, wq_t[h]).view(B, Lt, E_in)                     # data movement into the pad
-            HT[:, :, h, :Lt] = K.linear(vh, wo_h[h]).view(B, Lt, E_out).transpose(1, 2)
+        G[:, :, :Lt] = g_heads.view(H, B, Lt, E_in).permute(1, 0, 2, 3)
+        HT[:, :, :, :Lt] = h_heads.view(H, B, Lt, E_out).permute(1, 3, 0, 2)
         return K.xattn_operands(G.view(B * H * 16, E_in), HT.view(B * E_out, H * 16)) + (Lt,)
 
     def forward(self, enc_embs, query_embs, residual=None, kv=None, **kwargs):
