@@ -31,6 +31,13 @@
                             // operand reads, 5 no halo staging behind the first, 7 no MFMAs, 8 no output stores
 #endif
 
+// 1 (default since round 3): operand fragments one tap ahead, reads / weight loads woven between the MFMAs with
+// sched_group_barrier; 4.24 -> 4.18 ms per 2040 slot images on dense random data (A/B in one process, two rounds,
+// scripts/probes/conv16_ablate.hip -DLAYOUT=3): +1.4 %, same products in the same order (bit-identical)
+#ifndef TOCVP_CONV_WEAVE
+#define TOCVP_CONV_WEAVE 1
+#endif
+
 namespace {
 
 constexpr int ABL = TOCVP_ABLATE;
@@ -164,6 +171,42 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
         load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
         __syncthreads();
 
+#if TOCVP_CONV_WEAVE
+        // A fragments one tap ahead in a second register set, reads and weight loads woven between the MFMAs of
+        // the current tap (sched_group_barrier): the LDS latency of a tap's eight operand reads no longer sits in
+        // front of its first MFMA
+        f16x8 ah[2][4], al[2][4];
+        auto read_a = [&](int set, int tap) {
+            const int dy = ABL == 4 ? 0 : tap / 5, dx = ABL == 4 ? 0 : tap % 5;
+            const unsigned char* a_base = in_s + (dy * IW + dx) * ROWB;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ah[set][m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m]);
+                al[set][m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m] + OFF_LO);
+            }
+        };
+        read_a(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int cur = tap & 1;
+            if (ABL != 1) load_w(cur ^ 1, pass * NTAP + (tap + 1 < NTAP ? tap + 1 : tap));
+            if (tap + 1 < NTAP) read_a(cur ^ 1, tap + 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = mfma16(al[cur][m], bw[cur][0][n], acc[m][n]);      // Xl Wh
+                    acc[m][n] = mfma16(ah[cur][m], bw[cur][1][n], acc[m][n]);      // Xh Wl
+                    acc[m][n] = mfma16(ah[cur][m], bw[cur][0][n], acc[m][n]);      // Xh Wh
+                }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              // MFMA
+                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // weight fragment load
+                else if (tap + 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // operand read
+            }
+        }
+#else
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int cur = tap & 1;
@@ -186,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                     acc[m][n] = mfma16(ah[m], bw[cur][0][n], acc[m][n]);      // Xh Wh
                 }
         }
+#endif
     }
     __syncthreads();                            // the halo image is dead: reuse it as the store stage
 
