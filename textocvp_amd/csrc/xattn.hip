@@ -11,15 +11,18 @@
 // token (tokens per head padded to 16) and ONE kernel.  Padded caption positions take part as in the reference
 // (no key mask, attention.py:314); slots t >= Lt of a head are excluded from its softmax.
 //
-// One workgroup (4 waves) = 32 tokens of one sample:
-//   phase 0  LayerNorm of the 32 rows in registers (the arithmetic of layernorm_kernel, misc.hip), written as fp16
-//            operand planes (2^8 x = hi + lo) into LDS, rows padded to 2064 B (conflict-free ds_read_b128);
-//   phase 1  S^T = G_b LN(x)^T on the f16 matrix cores (three products per operand pair, fp32-class): wave w owns the
-//            32 score rows of heads 2w, 2w+1; G fragments come straight from L2 in MFMA-fragment order; with the
-//            caption slots on the accumulator ROWS the softmax over t is in-lane plus one cross-half exchange;
-//   phase 2  P goes back through LDS as operand planes (over the dead LN image), Y^T = HT_b P^T: wave w owns 128
-//            output columns; a lane holds four consecutive columns of one token per register quad, so bias,
-//            residual and the 16-byte stores come straight from the accumulators.
+// One workgroup (8 waves) = 64 tokens of one sample, 34 KB of LDS, ~100 registers -> four workgroups per CU:
+//   phase 0  LayerNorm statistics of the 64 rows (the arithmetic of layernorm_kernel, misc.hip);
+//   phase 1  S^T = G_b LN(x)^T on the f16 matrix cores (three products per operand pair, fp32-class), LN(x) staged in
+//            four chunks of 128 columns as fp16 operand planes (2^8 x = hi + lo, rows padded to 528 B: conflict-free
+//            ds_read_b128); a wave owns the 32 score rows of two heads for 32 tokens; G fragments come straight from
+//            L2 in MFMA-fragment order; with the caption slots on the accumulator ROWS the softmax over t is in-lane
+//            plus one cross-half exchange;
+//   phase 2  P goes back through LDS as operand planes (over the dead LN image), Y^T = HT_b P^T: a wave owns 64
+//            output columns of the 64 tokens; a lane holds four consecutive columns of one token per register quad,
+//            so bias, residual and the 16-byte stores come straight from the accumulators.
+// (The first version -- 4 waves, 32 tokens, the whole 512-column LN image in 66 KB of LDS, two workgroups per CU,
+// 512 KB of caption operands per 32 tokens -- measured 127 us at 128 x 300 tokens; this one:  see profiles/r03_xattn.md.)
 #include "common.h"
 
 namespace {
@@ -28,9 +31,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int E = 512, HEADS = 8, LP = 16, NP = HEADS * LP;          // 128 padded score columns
-constexpr int XROW = 2 * E * 2 + 16;                                 // LN image: [row][plane][k] + 16 B pad = 2064 B
-constexpr int PROW = 2 * NP * 2 + 16;                                // P image:  [row][plane][n] + 16 B pad = 528 B
+constexpr int TOK = 64;                                              // tokens per workgroup
+constexpr int KC = 128;                                              // LayerNorm image: columns per chunk
+constexpr int XROW = 2 * KC * 2 + 16;                                // [row][plane][KC] + 16 B pad = 528 B
+constexpr int PROW = 2 * NP * 2 + 16;                                // P image: [row][plane][n] + 16 B pad = 528 B
 constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
+static_assert(XROW == PROW, "the P image overlays the LayerNorm image");
 
 struct XArgs {
     const float* x; const float* gamma; const float* beta; float eps;
@@ -42,8 +48,189 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void xattn_collapsed_kernel(XArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[32 * XROW];
+// 8 waves, 64 tokens of one sample.  34 KB of LDS and ~100 registers: four workgroups (32 waves) per CU -- the kernel
+// is a chain of short dependent phases, what hides their latency is other workgroups.
+__global__ __launch_bounds__(512, 6) void xattn_collapsed_kernel(XArgs p, int gx) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TOK * XROW];
+    __shared__ float stats[TOK * 2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): all gx workgroups of a sample get linear
+    // ids with the same value mod 8, so a sample's 512 KB of caption operands are fetched into ONE L2 (dealt in
+    // launch order they landed on five XCDs: 58 % L2 misses, 328 MB instead of 66 MB from beyond L2).
+    const int L = blockIdx.x;
+    const int b = (L / (8 * gx)) * 8 + (L & 7), r0 = ((L >> 3) % gx) * TOK;
+    if (b >= p.B) return;
+    const float* xb = p.x + (size_t)b * p.Tq * E;
+
+    // ---- phase 0: LayerNorm statistics of rows 8 wave .. 8 wave + 7 (the arithmetic of layernorm_kernel, misc.hip;
+    // rows past Tq repeat the last row and are never stored)
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+        const int rl = wave * 8 + i;
+        const float* xr = xb + (size_t)min(r0 + rl, p.Tq - 1) * E;
+        f32x4 v[2];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u] = *reinterpret_cast<const f32x4*>(xr + (lane + 64 * u) * 4);
+            s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        }
+        const float mean = wave_sum64(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 d = v[u] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)E + p.eps);
+        if (lane == 0) {
+            stats[2 * rl] = mean;
+            stats[2 * rl + 1] = rstd;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: S^T = G LN(x)^T, LN(x) staged in chunks of 128 columns as fp16 operand planes.
+    // wave -> score rows n = 32 (wave & 3) + .. (heads 2 (wave & 3), + 1), tokens m = 32 (wave >> 2) + ..
+    const int nb = wave & 3, mb = wave >> 2;
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + nb) * (E / 16) * 2) * 64 + lane;
+    const unsigned char* xl = lds + (32 * mb + l31) * XROW + hh * 16;
+#pragma unroll 1
+    for (int ch = 0; ch < E / KC; ++ch) {
+        if (ch > 0) __syncthreads();                  // every wave has finished reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < (TOK * KC / 4) / 512; ++i) {
+            const int idx = t + 512 * i;
+            const int rl = idx / (KC / 4), c = ch * KC + (idx % (KC / 4)) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)min(r0 + rl, p.Tq - 1) * E + c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const float mean = stats[2 * rl], rstd = stats[2 * rl + 1];
+            const f32x4 o = (v - mean) * rstd * g + be;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = __builtin_amdgcn_fmed3f(o[e] * SA, -65504.f, 65504.f);
+                hi[e] = (_Float16)sc;
+                lo[e] = (_Float16)(sc - (float)hi[e]);
+            }
+            *reinterpret_cast<f16x4*>(lds + rl * XROW + (c - ch * KC) * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + rl * XROW + KC * 2 + (c - ch * KC) * 2) = lo;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + ks * 32);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(xl + KC * 2 + ks * 32);
+            const f16x8 wh = gf[(size_t)(ch * (KC / 16) + ks) * 128];
+            const f16x8 wl = gf[(size_t)(ch * (KC / 16) + ks) * 128 + 64];
+            sacc = mfma16(wh, al, sacc);
+            sacc = mfma16(wl, ah, sacc);
+            sacc = mfma16(wh, ah, sacc);
+        }
+    }
+    // softmax over the caption slots of each head: register r of lane half hh = slot t = 4 hh + (r & 3) + 8 ((r >> 2) & 1)
+    // of head 2 nb + (r >> 3); the other half of the slots sits in lane ^ 32
+    float pr[16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+            const float sv = sacc[8 * g + q] * p.scale;
+            pr[8 * g + q] = sv;
+            if (tt < p.Lt) mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+            const float e = tt < p.Lt ? expf(pr[8 * g + q] - mx) : 0.f;
+            pr[8 * g + q] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pr[8 * g + q] *= inv;
+    }
+    __syncthreads();                                  // every wave has finished reading the LN image
+    // P as operand planes: row m = 32 mb + l31, column n = 32 nb + 16 g + 8 u + 4 hh + {0..3}
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = pr[8 * g + 4 * u + e] * SA;
+                hi[e] = (_Float16)sc;
+                lo[e] = (_Float16)(sc - (float)hi[e]);
+            }
+            const int n = 32 * nb + 16 * g + 8 * u + 4 * hh;
+            *reinterpret_cast<f16x4*>(lds + (32 * mb + l31) * PROW + n * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + (32 * mb + l31) * PROW + NP * 2 + n * 2) = lo;
+        }
+    __syncthreads();
+
+    // ---- phase 2: Y^T tiles of this wave, one 32-column block at a time (keeps the kernel at 3 workgroups per CU):
+    // rows c = 64 wave + 32 j + .., columns m = 32 i + ..; register quad q of tile (j, i) = columns
+    // 64 wave + 32 j + 8 q + 4 hh .. + 3 of token r0 + 32 i + l31
+    const unsigned char* pl = lds + l31 * PROW + hh * 16;
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+        f32x16 yacc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+        const f16x8* hf = reinterpret_cast<const f16x8*>(p.Hf) +
+                          ((size_t)(b * (E / 32) + wave * 2 + j) * (NP / 16) * 2) * 64 + lane;
+#pragma unroll 2
+        for (int ks = 0; ks < NP / 16; ++ks) {
+            const f16x8 wh = hf[ks * 128], wl = hf[ks * 128 + 64];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROW + ks * 32);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROW + NP * 2 + ks * 32);
+                yacc[i] = mfma16(wh, al, yacc[i]);
+                yacc[i] = mfma16(wl, ah, yacc[i]);
+                yacc[i] = mfma16(wh, ah, yacc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = r0 + 32 * i + l31;
+            if (row < p.Tq) {
+                const float* xr = xb + (size_t)row * E;
+                float* yr = p.y + ((size_t)b * p.Tq + row) * E;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 64 * wave + 32 * j + 8 * q + 4 * hh;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + c);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = yacc[i][4 * q + e] * (1.f / (SA * SW)) + bv[e] + rv[e];
+                    *reinterpret_cast<f32x4*>(yr + c) = v;
+                }
+            }
+        }
+    }
+}
+
+// Small problems (fewer than one workgroup of the 64-token kernel per CU): 4 waves, 32 tokens, the whole 512-column
+// LayerNorm image in LDS (66 KB), no chunk loop -- a shorter chain of phases per workgroup (one sequence, 300 tokens:
+// 19 us against 31 us), twice the caption-operand traffic per token (irrelevant at this size).
+constexpr int XROW1 = 2 * E * 2 + 16;                                // [row][plane][512] + 16 B pad = 2064 B
+__global__ __launch_bounds__(256, 2) void xattn_collapsed_small_kernel(XArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[32 * XROW1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y, r0 = blockIdx.x * 32;
@@ -82,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_kernel(XArgs p) {
                 hi[e] = (_Float16)sc;
                 lo[e] = (_Float16)(sc - (float)hi[e]);
             }
-            *reinterpret_cast<f16x4*>(lds + rl * XROW + c * 2) = hi;
-            *reinterpret_cast<f16x4*>(lds + rl * XROW + E * 2 + c * 2) = lo;
+            *reinterpret_cast<f16x4*>(lds + rl * XROW1 + c * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + rl * XROW1 + E * 2 + c * 2) = lo;
         }
     }
     __syncthreads();
@@ -94,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_kernel(XArgs p) {
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     {
         const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + wave) * (E / 16) * 2) * 64 + lane;
-        const unsigned char* xl = lds + l31 * XROW + hh * 16;
+        const unsigned char* xl = lds + l31 * XROW1 + hh * 16;
         f16x8 gh = gf[0], gl = gf[64];
 #pragma unroll 4
         for (int ks = 0; ks < E / 16; ++ks) {
@@ -199,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_kernel(XArgs p) {
     }
 }
 
+
 }  // namespace
 
 extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, const float* beta, float eps,
@@ -206,14 +394,24 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
                                          int Tq, int E_, int heads, int Lt, float scale, void* stream) {
     TOCVP_CHECK_ARG(x && gamma && beta && Gfrag && Hfrag && bias && y);
     TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= LP);
-    TOCVP_CHECK_ARG(B <= 65535);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) || !tocvp_aligned16(beta) ||
         !tocvp_aligned16(bias) || !tocvp_aligned16(Gfrag) || !tocvp_aligned16(Hfrag))
         return TOCVP_EALIGN;
     if (B == 0 || Tq == 0) return TOCVP_OK;
     XArgs p{x, gamma, beta, eps, static_cast<const _Float16*>(Gfrag), static_cast<const _Float16*>(Hfrag), bias, y,
             B, Tq, Lt, scale * (1.f / (SA * SW))};
-    hipLaunchKernelGGL(xattn_collapsed_kernel, dim3((Tq + 31) / 32, B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), p);
+    const int gx = (Tq + TOK - 1) / TOK;
+    static const int ncu = []() {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    if ((long)B * gx < ncu && B <= 65535) {
+        hipLaunchKernelGGL(xattn_collapsed_small_kernel, dim3((Tq + 31) / 32, B), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), p);
+        return tocvp_launch_status();
+    }
+    hipLaunchKernelGGL(xattn_collapsed_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), p, gx);
     return tocvp_launch_status();
 }
