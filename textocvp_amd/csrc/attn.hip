@@ -10,6 +10,8 @@
 //    of the next MFMA  O^T += V^T P^T  -- no LDS round trip, no transposition of P.
 //  * K/V are streamed in 32-key tiles through LDS (coalesced 16-byte global loads); Q is staged
 //    once.  Padded strides (dh+4) make every ds_read_b128 conflict-free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -24,6 +26,7 @@ struct MhaArgs {
     const int32_t* key_len;
     void* Osplit; int nsplit;      // optional (B*Tq, nsplit, H*dh) bf16-plane output instead of O
     const float* bias;             // optional additive score bias (H, Tq, Tk), e.g. T5 relative positions
+    int xcd;                       // XCD-aware workgroup ids (TOCVP_MHA_XCD, default 1)
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -72,8 +75,14 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128;
+    // Linear workgroup ids are dealt round-robin over the 8 XCDs (private L2 each): the query blocks of one
+    // (batch, head) get ids with the same value mod 8, so the keys / values they all stream are fetched into ONE L2
+    // (three 128-query blocks at 300 tokens read the same 154 KB; dealt in launch order they hit three XCDs).
+    const int gx = (p.Tq + 127) / 128;
+    const int bh = p.xcd ? (blockIdx.x / (8 * gx)) * 8 + (blockIdx.x & 7) : blockIdx.x / gx;
+    if (bh >= p.B * p.H) return;
+    const int b = bh / p.H, head = bh % p.H;
+    const int q0 = (p.xcd ? (blockIdx.x >> 3) % gx : blockIdx.x % gx) * 128;
 
     const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + head * DH;
     const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
@@ -291,8 +300,9 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
         (Osplit && !tocvp_aligned16(Osplit)))
         return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
-    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias};
-    dim3 grid((Tq + 127) / 128, H, B);
+    static const int xcd = []() { const char* e = getenv("TOCVP_MHA_XCD"); return e ? atoi(e) : 1; }();
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd};
+    dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + 127) / 128)));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dh == 64) {
         if (qk16) hipLaunchKernelGGL((mha_f32_kernel<64, true>), grid, dim3(256), 0, s, p);

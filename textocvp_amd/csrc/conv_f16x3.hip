@@ -34,6 +34,11 @@
 // 1 (default since round 3): operand fragments one tap ahead, reads / weight loads woven between the MFMAs with
 // sched_group_barrier; 4.24 -> 4.18 ms per 2040 slot images on dense random data (A/B in one process, two rounds,
 // scripts/probes/conv16_ablate.hip -DLAYOUT=3): +1.4 %, same products in the same order (bit-identical)
+// 1 (default since round 3): the tiles of one slot image share an XCD (halo rows become L2 hits): 4.120 -> 4.085 ms per
+// 2040 slot images (A/B in one process, two rounds, scripts/probes/conv16_ablate.hip -DLAYOUT=3): +0.9 %
+#ifndef TOCVP_CONV_XCD
+#define TOCVP_CONV_XCD 1
+#endif
 #ifndef TOCVP_CONV_WEAVE
 #define TOCVP_CONV_WEAVE 1
 #endif
@@ -81,7 +86,15 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_x = p.W / TW, tiles = tiles_x * (p.H / TH);
+#if TOCVP_CONV_XCD
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  The `tiles` tiles of one slot image share
+    // halo rows (12 input rows for 8 output rows): give them linear ids with the same value mod 8, so the halo rows a
+    // neighbour already fetched are L2 hits instead of a second trip to HBM.  Ids past the last image idle.
+    const int img = (blockIdx.x / (8 * tiles)) * 8 + (blockIdx.x & 7), tile = (blockIdx.x >> 3) % tiles;
+    if (img >= p.nimg) return;
+#else
     const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+#endif
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
 
     // accumulator tile m = 2 * (row of the wave's pair) + (32-pixel half of the 64-pixel row)
@@ -593,7 +606,11 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
             hipLaunchKernelGGL((conv5x5_dec_f16x3_persistent_kernel<0, false>), grid, dim3(256), 0, s, a, ntiles);
         return tocvp_launch_status();
     }
+#if TOCVP_CONV_XCD
+    const dim3 grid((unsigned)((size_t)((nimg + 7) / 8) * 8 * (H / TH) * (W / TW)));
+#else
     const dim3 grid((unsigned)ntiles);
+#endif
     if (in_mode == 0)
         hipLaunchKernelGGL(conv5x5_dec_f16x3_kernel<0>, grid, dim3(256), 0, s, a);
     else
