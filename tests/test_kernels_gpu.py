@@ -642,13 +642,15 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
     assert int(ws[:1024].abs().sum()) == 0, "flag words must be zero again after the launch"
 
 
-@pytest.mark.parametrize("B,Tq,Lt", [(3, 300, 12), (2, 37, 5), (1, 30, 16)])
+@pytest.mark.parametrize("B,Tq,Lt", [(3, 300, 12), (2, 37, 5), (1, 30, 16), (61, 270, 12), (130, 140, 9)])
 def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt):
     """
     csrc/xattn.hip: LayerNorm + q projection + attention over the caption + output projection + residual in ONE
     kernel, with the projections folded into per-sample caption operands.  Against (a) an fp64 evaluation of the
     reference's TransformerDecoderBlock cross-attention half (attention.py:445-463, 303-319) and (b) this repo's
     four-kernel path on the same module (TextKV without collapsed operands); ragged Tq, Lt < 16 (masked slots).
+    The last two shapes fill the chip and take the 64-token-workgroup variant (B not a multiple of 8: idle ids of the
+    XCD-aware numbering; Tq not a multiple of 64), the first three the 32-token variant.
     """
     from textocvp_amd.models.Blocks.attention import TextKV, TransformerDecoderBlock
     k = _k()
