@@ -81,12 +81,14 @@ def test_gemm_rejects_bad_arguments():
 
 
 @pytest.mark.parametrize("rows,D,eps,with_add", [(4096 * 2, 32, 1e-5, True), (61, 128, 1e-3, False),
-                                                 (300, 512, 1e-6, False), (5, 128, 1e-8, False)])
+                                                 (300, 512, 1e-6, False), (5, 128, 1e-8, False),
+                                                 (4096 + 13, 128, 1e-3, True), (77, 64, 1e-5, False),
+                                                 (9, 32, 1e-5, False), (33, 256, 1e-5, False)])
 def test_layernorm(rows, D, eps, with_add):
     k = _k()
     x, g, b = rnd("lx", (rows, D), "normal", 3.0), 1 + rnd("lg", (D,), "uniform", 0.3), rnd("lb", (D,))
     add = rnd("la", (4096, D)) if with_add else None
-    xin = x + add.repeat(rows // 4096, 1) if with_add else x
+    xin = x + add.repeat(rows // 4096 + 1, 1)[:rows] if with_add else x
     ref = O.layer_norm(xin, g, b, eps)
     got = k.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), eps, add=add.to(DEV) if with_add else None)
     close(got, ref)

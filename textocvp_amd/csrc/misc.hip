@@ -64,6 +64,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm of NARROW rows (D = 32 / 64 / 128: the SAVi encoder's per-pixel LayerNorms over 4.2 M rows per chunk):
+// D/4 lanes per row (16 bytes each), 256/D rows per wave -- the one-wave-per-row kernel above moves only D*4 bytes per
+// wave instruction there (D = 32: 1.33 ms for 1 GB at 1024 images, 0.8 TB/s; this form 0.19 ms).  Same arithmetic
+// and the same reduction order per row as layernorm_kernel<0> (whose idle lanes add exact zeros), so the results
+// are bit-identical.
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ add, int add_rows,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               float* __restrict__ y, long rows, float eps) {
+    constexpr int LPR = D / 4;                       // lanes per row
+    const long row = (long)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    const int c = (threadIdx.x % LPR) * 4;
+    if (row >= rows) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + row * D + c);
+    if (add) v += *reinterpret_cast<const f32x4*>(add + (row % add_rows) * D + c);
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    const f32x4 d = v - mean;
+    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    *reinterpret_cast<f32x4*>(y + row * D + c) = d * rstd * g + b;
+}
+
 // T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * gamma   (no mean subtraction, no bias)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ gamma,
@@ -275,6 +306,20 @@ extern "C" int tocvp_layernorm_f32(const float* x, const float* add, int add_row
         !tocvp_aligned16(beta) || (add && !tocvp_aligned16(add)))
         return TOCVP_EALIGN;
     if (rows == 0) return TOCVP_OK;
+    if (D == 32 || D == 64 || D == 128) {
+        const dim3 grid(blocks_for(rows, 1024 / D));
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (D == 32)
+            hipLaunchKernelGGL(layernorm_narrow_kernel<32>, grid, dim3(256), 0, st, x, add, add_rows, gamma, beta, y,
+                               (long)rows, eps);
+        else if (D == 64)
+            hipLaunchKernelGGL(layernorm_narrow_kernel<64>, grid, dim3(256), 0, st, x, add, add_rows, gamma, beta, y,
+                               (long)rows, eps);
+        else
+            hipLaunchKernelGGL(layernorm_narrow_kernel<128>, grid, dim3(256), 0, st, x, add, add_rows, gamma, beta, y,
+                               (long)rows, eps);
+        return tocvp_launch_status();
+    }
     hipLaunchKernelGGL(layernorm_kernel<0>, dim3(blocks_for(rows, 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, add, add_rows, gamma, beta,
                        static_cast<void*>(y), rows, D, eps);
