@@ -118,6 +118,16 @@ int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* 
 int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
                             const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
                             int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);
+/* Same product with a caller-owned workspace (tocvp_gemm_wfrag_ws_bytes() bytes, 16-byte aligned, ZERO before its
+ * first use, one per stream that may run concurrently): with few output tiles (small evaluation batches: M <= ~600
+ * rows) the kernel splits K over idle CUs -- up to 16 slices, each workgroup parks its raw accumulators in `ws` and
+ * the last arriver of a tile adds the slices in slice order (deterministic; arrival counters re-arm themselves) and
+ * runs the epilogue.  ws == NULL: never split.  A is fp32 (M, K) with row stride lda; c_split as below. */
+size_t tocvp_gemm_wfrag_ws_bytes(void);
+int tocvp_gemm_f16wfrag_ws_f32(const void* A, int lda, const void* Wfrag, const float* bias, const float* R,
+                               int ldr, const float* rowvec, int rv_div, int rv_mod, int rv_flip, void* C,
+                               int c_split, int ldc, int M, int N, int K, int act, void* ws, size_t ws_bytes,
+                               void* stream);
 /*   a_split != 0: A is already split by its producer, (M, nsplit, K) bf16 planes (lda ignored);
  *   c_split != 0: C is written as (M, nsplit, N) bf16 planes for a following split GEMM
  *   (ldc ignored).  Splitting an activation once in its producer instead of once per column block

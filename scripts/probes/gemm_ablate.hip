@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i)
         tocvp_gemm_bf16wfrag_f32(A, planes, K, Wf, 22, bias, nullptr, 0, nullptr, 1, 1, 0, C, 0, N, M, N, K, 1, nullptr);
     hipEventRecord(e0);
-    const int reps = 10;
+    const int reps = argc > 5 ? atoi(argv[5]) : 10;
     for (int i = 0; i < reps; ++i)
         tocvp_gemm_bf16wfrag_f32(A, planes, K, Wf, 22, bias, nullptr, 0, nullptr, 1, 1, 0, C, 0, N, M, N, K, 1, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);

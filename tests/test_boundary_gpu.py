@@ -20,7 +20,7 @@ import torch
 
 from conftest import load_golden, max_abs
 from textocvp_amd import synth
-from textocvp_amd.evaluator import forward_eval, forward_eval_decomp, gather_metrics
+from textocvp_amd.evaluator import GraphedEval, forward_eval, forward_eval_decomp, gather_metrics
 from textocvp_amd.metrics import MetricTracker
 from textocvp_amd.setup_model import default_exp_params, load_checkpoint, setup_model, setup_predictor
 
@@ -181,6 +181,51 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def test_graph_replay_of_the_evaluation_is_bit_identical():
+    """ small batches are launch-bound from Python: GraphedEval captures forward_eval (+ an epilogue) per input
+    signature and replays it; every replay must equal the eager call on the same inputs bit for bit -- new videos,
+    new captions (the caption projections are part of the graph), new noise -- and a second signature gets a graph
+    of its own """
+    from textocvp_amd import kernels
+    torch.manual_seed(0)
+    exp = default_exp_params(num_slots=7, num_context=2, num_preds=4)
+    savi = setup_model(exp["model"]).eval()
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(savi, prefix="savi.")
+    synth.fill_module_(pred, prefix="pred.")
+    savi, pred = savi.to(DEV), pred.to(DEV)
+
+    def metrics(out):
+        B, P, C, H, W = out["pred_imgs"].shape
+        return kernels.psnr_ssim(out["pred_imgs"].reshape(B * P, C, H, W), out["targets"].reshape(B * P, C, H, W),
+                                 clamp01=True)
+
+    def inputs(B, seed):
+        videos = synth.synth_videos(B, 6, seed=seed).to(DEV)
+        tokens, lengths = synth.synth_captions(B, max_len=9, seed=seed)
+        return videos, {"caption_tokens": tokens.to(DEV), "caption_lengths": lengths.to(DEV),
+                        "init_noise": synth.synth_noise(B, 7, 128, seed=seed + 1).to(DEV), "caption": ["ignored"] * B}
+
+    graphed = GraphedEval(savi, pred, 2, 4, epilogue=metrics)
+    for B, seed in ((2, 5), (2, 6), (3, 7), (2, 8), (3, 9)):
+        videos, others = inputs(B, seed)
+        eager = forward_eval(savi, pred, videos, 2, 4, overlap_decode=False, **others)
+        eager_m = metrics(eager)
+        out = graphed(videos, **others)
+        for name in ("slot_history", "pred_slots", "pred_imgs", "masks", "recons_imgs", "targets"):
+            assert torch.equal(out[name], eager[name]), (name, B, seed)
+        assert torch.equal(out["epilogue"][0], eager_m[0]) and torch.equal(out["epilogue"][1], eager_m[1])
+    assert len(graphed._graphs) == 2
+    with pytest.raises(ValueError):
+        graphed(videos.cpu(), **others)
+    # new weights: the graphs (raw pointers to the old operand planes) are dropped and captured again
+    with torch.no_grad():
+        pred.predictor.predictor[0].mlp[0].weight.mul_(1.25)
+    eager = forward_eval(savi, pred, videos, 2, 4, overlap_decode=False, **others)
+    out2 = graphed(videos, **others)
+    assert len(graphed._graphs) == 1 and torch.equal(out2["pred_imgs"], eager["pred_imgs"])
 
 
 def test_rccl_branch_on_a_world_of_one_rank():

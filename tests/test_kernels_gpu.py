@@ -390,6 +390,37 @@ def test_gemm_f16x3_is_fp32_class(M, N, K):
     assert (small.cpu().double() - small_ref).abs().max().item() < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (30, 512, 2048), (300, 2048, 512), (270, 512, 512),
+                                   (301, 1536, 512), (12, 512, 64), (600, 512, 2048), (5, 128, 256)])
+def test_gemm_f16x3_split_k_of_the_small_batches(M, N, K, monkeypatch):
+    """ skinny f16x3 GEMMs split K over idle CUs (gemm_bf16.hip, SK): fp32-class against fp64, the same value as the
+    unsplit kernel to rounding, identical on every repetition (slices are added in slice order by whichever
+    workgroup arrives last), epilogue forms intact, arrival counters back at zero """
+    k = _k()
+    x, w, b = rnd("kx", (M, K)), rnd("kw", (N, K), "uniform", K ** -0.5), rnd("kb", (N,))
+    res, rv = rnd("kres", (M, N)), rnd("krv", (7, N))
+    xd, wd, bd, rd, rvd = (t.to(DEV) for t in (x, w, b, res, rv))
+    ref = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()
+    monkeypatch.setattr(k, "_GEMM_KSPLIT", False)
+    plain = k.linear(xd, wd, bd, act=k.ACT_RELU, residual=rd, precision="f16x3")
+    plain_rv = k.linear(xd, wd, bd, rowvec=rvd, rv_div=3, precision="f16x3")
+    monkeypatch.setattr(k, "_GEMM_KSPLIT", True)
+    got = k.linear(xd, wd, bd, act=k.ACT_RELU, residual=rd, precision="f16x3")
+    scale = ref.abs().max().item()
+    err, err_plain = (got.cpu().double() - ref).abs().max().item(), (plain.cpu().double() - ref).abs().max().item()
+    print(f"split-K gemm {M}x{N}x{K}: err {err:.2e} (unsplit {err_plain:.2e}) at scale {scale:.3g}")
+    assert err < max(2.5 * err_plain, 2e-6 * scale)
+    for _ in range(20):
+        assert torch.equal(k.linear(xd, wd, bd, act=k.ACT_RELU, residual=rd, precision="f16x3"), got)
+    close(k.linear(xd, wd, bd, rowvec=rvd, rv_div=3, precision="f16x3"), plain_rv, tol=2e-6)
+    planes = k.linear(xd, wd, bd, precision="f16x3", out_split=22)
+    planes_ref = k.linear(xd, wd, bd, precision="f16x3")
+    hi_lo = planes.planes.float().view(M, 2, N).sum(1) / 256.0
+    close(hi_lo, planes_ref, tol=2e-6)
+    wk = k._ksplit_workspace(xd.device)[0]
+    assert int(wk[:1024].view(torch.int32).abs().sum()) == 0
+
+
 def test_gemm_f16x3_range_behaviour(monkeypatch):
     """ outside |x| < 255 the fp16 planes saturate: 11-bit accuracy up to 511, finite (never inf/nan)
     beyond; TOCVP_CHECK_RANGE turns the silent saturation into an error """

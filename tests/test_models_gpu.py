@@ -355,7 +355,10 @@ def test_e2e_against_oracle_fresh_inputs(k7):
     assert max_abs(out["slot_history"].cpu(), hist) < 1e-4
     assert max_abs(out["pred_slots"].cpu(), preds) < 1e-4
     assert max_abs(out["pred_imgs"].cpu(), imgs) < 1e-4
-    assert_same_slot_assignment(out["masks"], masks.argmax(dim=1), "e2e fresh inputs vs oracle (K=7, B=3)")
+    # one pixel whose two largest masks differ by 2.1e-7 in the oracle (a few fp32 ulps) goes the other way since the
+    # skinny GEMMs of small batches add their K slices in a different order (split-K, gemm_bf16.hip): a named tie
+    assert_same_slot_assignment(out["masks"], masks.argmax(dim=1), "e2e fresh inputs vs oracle (K=7, B=3)",
+                                ties=1, tie_margin=5e-7)
 
 
 @torch.no_grad()

@@ -655,8 +655,9 @@ def test_graph_replayed_steps_equal_eager_steps():
     for n in res[0][1]:
         # three steps of at most lr = 1e-4.  Not bit-identical: two float-atomic reductions in the backward pass
         # make gradients reproducible to ~1e-10, and Adam turns a near-zero gradient g into lr * g / (|g| + eps),
-        # i.e. amplifies that by lr / eps = 1e4 on the few elements whose gradient vanishes
-        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 1e-5, n
+        # i.e. amplifies that by lr / eps = 1e4 on the few elements whose gradient vanishes (worst case 3 lr = 3e-4;
+        # seen: up to 1.2e-5 on one element of one MLP weight)
+        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 5e-5, n
 
 
 @pytest.mark.parametrize("M,N,Kd,tA,tB,ld_pad", [(70, 50, 33, False, False, 0), (64, 64, 64, True, False, 0),

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 // timing experiments only (scripts/probes/gemm_ablate.hip): 1 = no weight-fragment loads in the k-loop,
 // 2 = no A loads, 3 = no A conversion / LDS stores, 4 = no MFMAs (and no LDS reads), 5 = no epilogue.
@@ -26,6 +27,9 @@ constexpr int GABL = TOCVP_GEMM_ABLATE;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+constexpr size_t WFRAG_WS_CTR_BYTES = 4096;                 // split-K workspace: 1024 tile counters ...
+constexpr int WFRAG_WS_RECORDS = 1024;                      // ... and 1024 accumulator records of 16 KB
+
 struct GemmArgs {
     const float* A; int lda;
     const __bf16* W;             // (N, NS, K)
@@ -36,6 +40,9 @@ struct GemmArgs {
     int M, N, K, act;
     int a_split;                 // A is (M, NS, K) bf16 planes (producer already split it)
     int c_split;                 // write C as (M, NS, N) bf16 planes instead of fp32
+    int ksplit;                  // split-K (wfrag 64 x 64 kernel, SK = true): grid.y slices of K, > 1 needs the workspace
+    float* ws_part;              // [tile][slice] raw accumulator records (lane order), 16 KB each
+    unsigned* ws_ctr;            // [tile] arrival counters, zero between launches (the last arriver re-arms its own)
 };
 
 // R operand of the epilogue: residual (added) or, for TOCVP_ACT_GATE, the tensor whose sign gates the output
@@ -242,13 +249,27 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_split_kernel(GemmArgs
 //     ds_write pipe was the limiter of the LDS-staged split kernels) and halves the LDS footprint.
 //     B fragments are prefetched one whole k-tile (2 k-steps) ahead in registers.
 // ------------------------------------------------------------------------------------------------
-template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool ASPLIT, bool F16>
+//
+// SK = true (64 x 64 tiles, fp32 A, f16x3): split-K for the skinny GEMMs of small batches (M <= 300 rows x N = 512
+// columns is 40 workgroups on 256 CUs, each walking K = 2048 as 64 dependent k-tiles of one memory round trip each:
+// 47 us however few rows there are).  blockIdx.y owns K / ksplit; every workgroup parks its raw accumulators in the
+// workspace (lane order, 16-byte stores), counts itself in, and the LAST arriver of a tile adds the ksplit records
+// in slice order 0 .. ksplit-1 (its own included, re-read: the result does not depend on who arrives last) and runs
+// the normal epilogue.  Hand-off per cdna_hip_programming.md Guideline 16 (drain, barrier, agent release, counter;
+// agent acquire, barrier, plain loads; the records are stored write-through, recipe R1, instead of a release).
+//
+// BK_ = 64 (fp32 A only): a deeper k-tile for the 64 x 64 kernel of the small batches -- half the barriers and load
+// waits per K; the MFMA sequence per output element is the same, so results are bit-identical across BK.
+template <int NS, int BM, int BN, int WM, int WN, int NW, int MINW, bool ASPLIT, bool F16, bool SK = false,
+          int BK_ = 32>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs p) {
     using E = Elem<F16>;
     using ET = typename E::T;
     using EV8 = typename E::V8;
     using EV4 = typename E::V4;
-    constexpr int BK = 32;
+    constexpr int BK = BK_;
+    constexpr int KSTEPS = BK / 16;                  // 16-deep MFMA k-steps per k-tile
+    static_assert(BK == 32 || !ASPLIT, "pre-split A tiles are staged 32 deep");
     constexpr int ACH = BM * NS * 4;                 // 16-byte chunks of a pre-split A tile
     constexpr int RAS = (ACH + NW * 64 - 1) / (NW * 64);
     constexpr int NT = NW * 64;
@@ -286,8 +307,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
     // VGPRs + a v_lshl_add_u64 per load and pushed the kernel into scratch spills; a spilled
     // address reload inside the loop is a VMEM op whose s_waitcnt vmcnt(0) drains the whole
     // prefetch (measured: the k-loop ran 3x slower than its MFMA time).
-    const char* const a_bytes = reinterpret_cast<const char*>(p.A);
-    const char* const w_bytes = reinterpret_cast<const char*>(p.W);
+    const int nk = SK ? (p.K / BK) / p.ksplit : p.K / BK;   // k-tiles of this workgroup (even, host-checked)
+    const int kt0 = SK ? (int)blockIdx.y * nk : 0;
+    const char* const a_bytes = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * BK * (ASPLIT ? 2 : 4);
+    const char* const w_bytes = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * (KSTEPS * NS * 64 * 16);
     constexpr int NRA = ASPLIT ? RAS : RA;
     unsigned voff_a[NRA];
 #pragma unroll
@@ -352,10 +375,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         }
     };
     // B fragments of one k-tile: [ks in tile][column block][plane]
-    auto gload_b = [&](EV8 (&b)[2][NI][NS], int kt) {
-        const char* base = w_bytes + (size_t)kt * (2 * NS * 64 * 16);    // uniform
+    auto gload_b = [&](EV8 (&b)[KSTEPS][NI][NS], int kt) {
+        const char* base = w_bytes + (size_t)kt * (KSTEPS * NS * 64 * 16);    // uniform
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -372,10 +395,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](const EV8 (&b)[2][NI][NS], int buf) {
+    auto compute = [&](const EV8 (&b)[KSTEPS][NI][NS], int buf) {
         const unsigned char* a_base = As + buf * BM * ROWB + (wm * WM + l31) * ROWB + h * 16;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             EV8 a[MI][NS];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -395,8 +418,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         }
     };
 
-    const int nk = p.K / BK;
-    EV8 b0[2][NI][NS], b1[2][NI][NS];
+    EV8 b0[KSTEPS][NI][NS], b1[KSTEPS][NI][NS];
     // Branch-free software pipeline (nk even, host-checked; prefetch indices clamped so the tail
     // re-fetches tile nk-1): A one k-tile ahead (registers -> LDS), weight fragments one k-tile
     // ahead in registers, two k-tiles per iteration so the register sets have static names.
@@ -420,6 +442,73 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         __syncthreads();
     }
     if (GABL == 5) return;
+
+    if (SK && p.ksplit > 1) {
+        constexpr int REC = NT * MI * NI * 16;                         // floats per record
+        const int S = p.ksplit;
+        float* rec = p.ws_part + ((size_t)bid * S) * REC + t * 4;
+        {
+            // write-through (sc1) 16-byte stores: the records leave the XCD's L2 as they are written, so no release
+            // fence is needed (its L2 write-back costs ~6.5 us with 16 KB freshly dirtied per workgroup)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ws_part, 0, WFRAG_WS_RECORDS * REC * 4, 0x00020000);
+            const unsigned off0 = (unsigned)((((size_t)bid * S + blockIdx.y) * REC + t * 4) * sizeof(float));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
+                                                               off0 + ((i * NI + j) * 4 + q) * (NT * 16), 0, 16);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains its stores
+        __syncthreads();
+        unsigned* arrived = reinterpret_cast<unsigned*>(lds);          // the A images are dead
+        if (t == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.ws_ctr + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)(S - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.ws_ctr + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            *arrived = old;
+        }
+        __syncthreads();
+        if (*arrived != (unsigned)(S - 1)) return;
+        __syncthreads();                                               // the staging epilogue overwrites lds[0..]
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // records in groups of four (two when S = 2): all loads of a group in flight together -- one memory round
+        // trip per group, not per slice -- then added in slice order
+        constexpr int NV = MI * NI * 4;
+        auto add_group = [&](auto gc, int s0) __attribute__((always_inline)) {
+            constexpr int G = decltype(gc)::value;
+            f32x4 v[G][NV];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+                    v[g][e] = *reinterpret_cast<const f32x4*>(rec + (size_t)(s0 + g) * REC + e * (NT * 4));
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[e / (NI * 4)][(e / 4) % NI][4 * (e % 4) + u] += v[g][e][u];
+        };
+        if (S == 2) {
+            add_group(std::integral_constant<int, 2>{}, 0);
+        } else {
+            for (int s0 = 0; s0 < S; s0 += 4) add_group(std::integral_constant<int, 4>{}, s0);
+        }
+    }
 
     // ---- fast epilogue (no row-vector, fp32 output): stage each 32-row block of the wave's tile in
     // LDS (the A images are dead after the loop's last barrier) and write it back as dwordx4 rows:
@@ -709,6 +798,43 @@ int launch_wfrag(const GemmArgs& p, hipStream_t s) {
     return tocvp_launch_status();
 }
 
+// split-K plan of the 64 x 64 kernel: slices double while the grid stays within ~2 workgroups per CU, every slice
+// keeps >= 4 k-tiles (an even count: the loop takes two per iteration) and the records fit the workspace
+static int ksplit_wgs() {
+    static const int v = []() {
+        const char* e = getenv("TOCVP_GEMM_KSPLIT_WGS");
+        return e ? atoi(e) : 256;
+    }();
+    return v;
+}
+static int pick_ksplit(const GemmArgs& p, int bk) {
+    const int tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64), nk = p.K / bk, least = bk == 32 ? 4 : 2;
+    int S = 1;
+    while (S < 16 && tiles * S * 2 <= ksplit_wgs() && nk % (S * 4) == 0 && nk / (S * 2) >= least) S *= 2;   // 1 .. 16
+    return (tiles <= 1024 && tiles * S <= WFRAG_WS_RECORDS) ? S : 1;
+}
+// k-tile depth of the 64 x 64 kernel: 64 where it leaves an even number of k-tiles (the loop takes two per iteration),
+// else 32; TOCVP_GEMM_SMALL_BK=32 pins the shallow form.  Measured (scripts/ksplit_bench.py, graph replay, us):
+// 300x512x2048 split-K 15.1 / 12.7 / 13.8 at BK 32 / 64 / 128, 2400x512x2048 41.4 / 36.4 / 37.7, K = 512 shapes equal at
+// 32 and 64 and 10-15 % slower at 128 (216 VGPRs, 66 KB LDS) -- the 128-deep form is not built.
+static int pick_small_bk(int K) {
+    static const int pinned = []() {
+        const char* e = getenv("TOCVP_GEMM_SMALL_BK");
+        return e ? atoi(e) : 0;
+    }();
+    return (pinned != 32 && K % 128 == 0) ? 64 : 32;
+}
+
+template <int BK>
+int launch_small_f16(const GemmArgs& p, hipStream_t s) {
+    GemmArgs q = p;
+    q.ksplit = p.ws_part ? pick_ksplit(p, BK) : 1;
+    const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64;
+    hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<2, 64, 64, 32, 32, 4, 1, false, true, true, BK>),
+                       dim3(ntm * ntn, q.ksplit), dim3(256), 0, s, q);
+    return tocvp_launch_status();
+}
+
 // 128 x 128 tiles only when there are enough of them: below this count the 64 x 64 kernel fills the CUs better
 static long small_below() {
     static const long v = []() {
@@ -730,7 +856,12 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
         hipLaunchKernelGGL(gemm_f16_planes_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
         return tocvp_launch_status();
     }
-    if (big_tiles < small_below()) return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
+    if (big_tiles < small_below()) {
+        if (!p.a_split) {
+            return pick_small_bk(p.K) == 64 ? launch_small_f16<64>(p, s) : launch_small_f16<32>(p, s);
+        }
+        return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
+    }
     static const int variant = []() {
         const char* e = getenv("TOCVP_GEMM_VARIANT");
         return e ? atoi(e) : 0;
@@ -842,6 +973,34 @@ extern "C" int tocvp_split_weights_frag_f16(const float* w, void* out, int N, in
     hipLaunchKernelGGL(split_weights_frag_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, static_cast<_Float16*>(out), n, K, 2);
     return tocvp_launch_status();
+}
+
+extern "C" size_t tocvp_gemm_wfrag_ws_bytes(void) {
+    return WFRAG_WS_CTR_BYTES + (size_t)WFRAG_WS_RECORDS * 256 * 16 * sizeof(float);
+}
+
+extern "C" int tocvp_gemm_f16wfrag_ws_f32(const void* A, int lda, const void* Wfrag, const float* bias,
+                                          const float* R, int ldr, const float* rowvec, int rv_div,
+                                          int rv_mod, int rv_flip, void* C, int c_split, int ldc, int M, int N,
+                                          int K, int act, void* ws, size_t ws_bytes, void* stream) {
+    TOCVP_CHECK_ARG(A && Wfrag && C);
+    TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0 && lda >= K);
+    TOCVP_CHECK_ARG(c_split || ldc >= N);
+    TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
+    TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
+    TOCVP_CHECK_ARG((act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU) || (act == TOCVP_ACT_GATE && R != nullptr));
+    TOCVP_CHECK_ARG(c_split || ((ldc & 3) == 0 && tocvp_aligned16(C)));
+    TOCVP_CHECK_ARG(ws == nullptr || (ws_bytes >= tocvp_gemm_wfrag_ws_bytes() && tocvp_aligned16(ws)));
+    if ((lda & 3) || !tocvp_aligned16(A) || !tocvp_aligned16(Wfrag)) return TOCVP_EALIGN;
+    if (M == 0) return TOCVP_OK;
+    GemmArgs p{static_cast<const float*>(A), lda, static_cast<const __bf16*>(Wfrag), bias, R, ldr,
+               rowvec, rv_div, rv_mod, rv_flip, static_cast<float*>(C), ldc, M, N, K, act, 0, c_split ? 1 : 0,
+               1, nullptr, nullptr};
+    if (ws) {
+        p.ws_ctr = static_cast<unsigned*>(ws);
+        p.ws_part = reinterpret_cast<float*>(static_cast<char*>(ws) + WFRAG_WS_CTR_BYTES);
+    }
+    return dispatch_wfrag_f16(p, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,

@@ -102,6 +102,87 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
             "targets": targets, "masks": masks, "recons": recons, "recons_imgs": recons_imgs}
 
 
+class GraphedEval:
+    """
+    ``forward_eval`` replayed from a captured HIP graph: the small-batch form of the path.
+
+    One sequence is ~2400 dependent kernel launches of a few microseconds each; enqueued from Python the host is the
+    bottleneck (B = 1: 46 ms eager against 28 ms of device time).  The first call with a new input signature (shapes
+    and dtypes of ``videos`` and of every tensor in ``others``) runs one eager pass on private copies of the inputs
+    -- range calibration, weight splits, workspaces, the side stream -- then captures the same pass into a graph;
+    every later call copies its inputs into those buffers and replays.  Same kernels in the same order on the same
+    arithmetic: results are bit-identical to the eager call (tests/test_boundary_gpu.py).
+
+    A graph holds raw pointers to the weights' derived forms (operand planes, fused tables): when a parameter or buffer
+    of either model is replaced, moved or modified (``load_state_dict``, ``.to``, an optimiser step) every graph is
+    dropped and the next call captures again.
+
+    The returned tensors are the graph's own output buffers: they are overwritten by the next call with the same
+    signature, so consume (or clone) them first.  ``epilogue(out) -> tensor or tuple`` (optional) runs inside the
+    capture on the result dictionary, e.g. the fused PSNR / SSIM step; its value is returned under "epilogue".
+    Non-tensor entries of ``others`` (the caption strings the reference also passes) only reach the capturing call.
+    The decoder is not overlapped with the rollout by default here: under replay the serial order was the faster
+    one at every batch measured (B = 1: 28.1 vs 32.7 ms, B = 8: 66.3 vs 67.2, B = 32: 185.0 vs 187.4).
+    """
+
+    def __init__(self, decomp_model, predictor, num_context, num_preds, overlap_decode=False, epilogue=None):
+        self.decomp_model, self.predictor = decomp_model, predictor
+        self.num_context, self.num_preds = num_context, num_preds
+        self.overlap_decode, self.epilogue = overlap_decode, epilogue
+        self._graphs, self._weights = {}, None
+
+    def _weights_signature(self):
+        sig = []
+        for m in (self.decomp_model, self.predictor):
+            sig += [(t.data_ptr(), t._version) for t in m.parameters()]
+            sig += [(t.data_ptr(), t._version) for t in m.buffers()]
+        return hash(tuple(sig))
+
+    @staticmethod
+    def _signature(videos, others):
+        sig = [("videos", tuple(videos.shape), videos.dtype)]
+        sig += [(k, tuple(v.shape), v.dtype) for k, v in sorted(others.items()) if torch.is_tensor(v)]
+        return tuple(sig)
+
+    def _run(self, videos, others):
+        out = forward_eval(self.decomp_model, self.predictor, videos, self.num_context, self.num_preds,
+                           overlap_decode=self.overlap_decode, **others)
+        if self.epilogue is not None:
+            out["epilogue"] = self.epilogue(out)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, videos, **others):
+        if not videos.is_cuda:
+            raise ValueError("GraphedEval replays a HIP graph: the inputs must live on the GPU")
+        weights = self._weights_signature()
+        if weights != self._weights:
+            self._graphs, self._weights = {}, weights
+        key = self._signature(videos, others)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_v = videos.clone()
+            static_o = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in others.items()}
+            self._run(static_v, static_o)                       # eager pass: calibration, caches, workspaces
+            torch.cuda.synchronize(videos.device)
+            static_v.copy_(videos)                              # new tensor versions: no cached caption projections
+            for k, v in others.items():
+                if torch.is_tensor(v):
+                    static_o[k].copy_(v)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run(static_v, static_o)
+            entry = (static_v, static_o, graph, out)
+            self._graphs[key] = entry
+        static_v, static_o, graph, out = entry
+        static_v.copy_(videos)
+        for k, v in others.items():
+            if torch.is_tensor(v):
+                static_o[k].copy_(v)
+        graph.replay()
+        return out
+
+
 @torch.no_grad()
 def forward_eval_decomp(decomp_model, videos, metric_tracker=None, **others):
     """

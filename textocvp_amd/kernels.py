@@ -55,6 +55,11 @@ _SIGNATURES = {
     "tocvp_gemm_f16planes_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_gemm_wfrag_ws_bytes": (ctypes.c_size_t, []),
+    "tocvp_gemm_f16wfrag_ws_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "tocvp_gemm_f16planes_ws_bytes": (ctypes.c_size_t, []),
     "tocvp_gemm_f16planes_ws_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -481,6 +486,25 @@ def _split_weight(w, nsplit, frag=False):
     return out
 
 
+# split-K of the skinny f16x3 GEMMs (gemm_bf16.hip, SK = true): TOCVP_GEMM_KSPLIT=0 turns it off.  The workspace
+# (arrival counters + accumulator records, 16.8 MB) is per device AND per stream -- two streams may run skinny GEMMs
+# at the same time (decoder overlap) -- and must start zeroed; the kernels leave the counters at zero.
+_GEMM_KSPLIT = os.environ.get("TOCVP_GEMM_KSPLIT", "1") != "0"
+_GEMM_KSPLIT_MAX_ROWS = 4096          # above this the tile count alone fills the CUs (the library would not split)
+_KSPLIT_WS = {}
+
+
+def _ksplit_workspace(device, stream=None):
+    """ (tensor, pointer, bytes) of the zero-initialised split-K workspace of this device and stream """
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
+    rec = _KSPLIT_WS.get(key)
+    if rec is None:
+        nbytes = lib().tocvp_gemm_wfrag_ws_bytes()
+        wk = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+        rec = _KSPLIT_WS[key] = (wk, ctypes.c_void_p(wk.data_ptr()), nbytes)
+    return rec
+
+
 # --------------------------------------------------------------------------------------------
 # tensor-level wrappers
 # --------------------------------------------------------------------------------------------
@@ -539,6 +563,17 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
             lib().tocvp_gemm_f16planes_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
                                            int(bool(out_split)), N, M, N, K, int(act), _stream()),
             "tocvp_gemm_f16planes_f32"))
+    elif frag_ok and nsplit == 22 and not pre_split and _GEMM_KSPLIT and M <= _GEMM_KSPLIT_MAX_ROWS:
+        # few output tiles (small batches): split-K over idle CUs through a per-stream workspace
+        ws = _split_weight(w, nsplit, frag=True)
+        st = torch.cuda.current_stream(w.device).cuda_stream
+        _, wk_ptr, wk_bytes = _ksplit_workspace(w.device, st)
+        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+            lib().tocvp_gemm_f16wfrag_ws_f32(_ptr(x2), K, _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
+                                             int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out),
+                                             int(bool(out_split)), N, M, N, K, int(act), wk_ptr,
+                                             wk_bytes, ctypes.c_void_p(st)),
+            "tocvp_gemm_f16wfrag_ws_f32"))
     elif frag_ok:
         ws = _split_weight(w, nsplit, frag=True)
         _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(

@@ -151,8 +151,13 @@ class SlotAttention(nn.Module):
             kv = kv.planes.view(*kv.shape[:-1], 2, kv.shape[-1])
         planes = kv.dtype == torch.float16
         N = kv.shape[1]
-        if self._ws is None or self._ws_key != (B, N, slots.device):          # ticket words zeroed once per shape
-            self._ws, self._ws_key = K.slot_attn_workspace(B, N, slots.device), (B, N, slots.device)
+        # ticket words zeroed once per shape; every shape keeps its workspace for the life of the module -- a captured
+        # graph (evaluator.GraphedEval) holds the raw pointer, so a workspace must never be freed behind it
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get((B, N, slots.device))
+        if ws is None:
+            ws = self._ws[(B, N, slots.device)] = K.slot_attn_workspace(B, N, slots.device)
         attn = None
         for _ in range(num_iters):
             prev = slots
@@ -160,10 +165,10 @@ class SlotAttention(nn.Module):
             if self.store_attention_masks:
                 attn = torch.empty((B, Ks, N), device=slots.device, dtype=torch.float32)
             if planes:
-                upd = K.slot_attn_iter_planes(q, kv, self.scale, self.epsilon, attn_out=attn, ws=self._ws)
+                upd = K.slot_attn_iter_planes(q, kv, self.scale, self.epsilon, attn_out=attn, ws=ws)
             else:
                 upd = K.slot_attn_iter(q, kv[..., :D], kv[..., D:], self.scale, self.epsilon, attn_out=attn,
-                                       ws=self._ws)
+                                       ws=ws)
             gi = K.linear(upd, self.gru.weight_ih, self.gru.bias_ih)
             gh = K.linear(prev, self.gru.weight_hh, self.gru.bias_hh)
             slots = K.gru_gates(gi, gh, prev)
