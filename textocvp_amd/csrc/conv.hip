@@ -219,22 +219,31 @@ __global__ __launch_bounds__(256) void conv5x5_in3_kernel(const float* __restric
 // WAVE-UNIFORM indices from a repacked [tap][c][4] table, so hipcc keeps them on the scalar path
 // (s_load + v_fmac with an SGPR operand) instead of spending an LDS broadcast read per FMA group;
 // all global loads of a halo tile are issued back to back before the first conversion.
+#ifndef TOCVP_DT_ABLATE
+#define TOCVP_DT_ABLATE 0                 // timing ablations (scripts/probes/dec_tail_ablate.hip): 1 no halo fetch,
+#endif                                    // 2 one weight group for every tap / channel, 3 no FMAs
+constexpr int DT_ABL = TOCVP_DT_ABLATE;
 constexpr int DT_H = 16, DT_W = 16, DT_C = 64, DT_CC = 32, DT_CS = DT_CC + 4;
 constexpr int DT_IH = DT_H + 2, DT_IW = DT_W + 2;
 
-__global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void dec_tail_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ wq,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ recons_imgs,
                                                           float* __restrict__ recons,
-                                                          float* __restrict__ masks, int K, int H,
+                                                          float* __restrict__ masks, int F, int K, int H,
                                                           int W) {
     __shared__ __attribute__((aligned(16))) float in_s[DT_IH * DT_IW * DT_CS];
-    __shared__ float alpha_s[32 * 256];
     const int t = threadIdx.x;
-    const int f = blockIdx.y;
+    // XCD-aware ids: workgroups are dealt round-robin over the 8 XCDs, so the tiles of ONE frame take ids that are
+    // equal mod 8 -- neighbouring tiles walk the same slot images at the same time and their halo rows then hit
+    // that XCD's L2 instead of being fetched again from HBM (27 % of the tile's bytes).  Frames padded to 8.
+    const int tiles = (H / DT_H) * (W / DT_W);
+    const int L = blockIdx.x, j = L >> 3;
+    const int f = (j / tiles) * 8 + (L & 7), tile = j % tiles;
+    if (f >= F) return;
     const int tiles_x = W / DT_W;
-    const int ty0 = (blockIdx.x / tiles_x) * DT_H, tx0 = (blockIdx.x % tiles_x) * DT_W;
+    const int ty0 = (tile / tiles_x) * DT_H, tx0 = (tile % tiles_x) * DT_W;
     const int py = t / DT_W, px = t % DT_W;
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)(ty0 + py) * W + tx0 + px;
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restric
     f32x4 tv[NIT];
     auto fetch = [&](int step) {
         const float* xi = x + ((size_t)f * K + (step >> 1)) * HW * DT_C + (step & 1) * DT_CC;
+        if (DT_ABL == 1 && step > 0) return;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {                          // batched, clamped loads
             const int i = min(t + it * 256, DT_IH * DT_IW * F4 - 1);
@@ -288,7 +298,11 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restric
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(ip + 4 * c4);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float* w4 = wt + (4 * c4 + u) * 4;
+                    const float* w4 = DT_ABL == 2 ? wq : wt + (4 * c4 + u) * 4;
+                    if (DT_ABL == 3) {
+                        acc[u] += xv[u];
+                        continue;
+                    }
                     acc[0] = fmaf(xv[u], w4[0], acc[0]);
                     acc[1] = fmaf(xv[u], w4[1], acc[1]);
                     acc[2] = fmaf(xv[u], w4[2], acc[2]);
@@ -301,25 +315,24 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(const float* __restric
             ro[0] = acc[0];
             ro[HW] = acc[1];
             ro[2 * HW] = acc[2];
-            alpha_s[k * 256 + t] = acc[3];
+            masks[((size_t)f * K + k) * HW + pix] = acc[3];          // raw alpha, normalised in place below
             acc = bv;
         }
     }
 
-    // softmax over slots (exact two-pass, as F.softmax) + compositing
+    // softmax over slots (exact two-pass, as F.softmax) + compositing.  The raw alphas of this pixel sit in its own
+    // `masks` words (written by this thread: no other thread or workgroup touches them), not in 32 KB of LDS -- the
+    // halo tile alone leaves room for three workgroups per CU.
+    float* mp = masks + (size_t)f * K * HW + pix;
     float m = -1.0e30f;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, alpha_s[k * 256 + t]);
+    for (int k = 0; k < K; ++k) m = fmaxf(m, mp[(size_t)k * HW]);
     float sum = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float e = expf(alpha_s[k * 256 + t] - m);
-        alpha_s[k * 256 + t] = e;
-        sum += e;
-    }
+    for (int k = 0; k < K; ++k) sum += expf(mp[(size_t)k * HW] - m);
     const float inv = 1.0f / sum;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     for (int k = 0; k < K; ++k) {
-        const float mk = alpha_s[k * 256 + t] * inv;
-        masks[((size_t)f * K + k) * HW + pix] = mk;
+        const float mk = expf(mp[(size_t)k * HW] - m) * inv;
+        mp[(size_t)k * HW] = mk;
         const float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
         c0 += ro[0] * mk;
         c1 += ro[HW] * mk;
@@ -399,7 +412,7 @@ extern "C" int tocvp_dec_tail_f32(const float* x, const float* w, const float* b
     hipLaunchKernelGGL(dec_tail_pack_kernel, dim3((9 * DT_C * 4 + 255) / 256), dim3(256), 0, s, w, wq,
                        DT_C);
     if (hipGetLastError() != hipSuccess) return TOCVP_ELAUNCH;
-    hipLaunchKernelGGL(dec_tail_kernel, dim3((H / DT_H) * (W / DT_W), F), dim3(256), 0, s, x,
-                       static_cast<const float*>(wq), bias, recons_imgs, recons, masks, K, H, W);
+    hipLaunchKernelGGL(dec_tail_kernel, dim3((H / DT_H) * (W / DT_W) * ((F + 7) / 8 * 8)), dim3(256), 0, s, x,
+                       static_cast<const float*>(wq), bias, recons_imgs, recons, masks, F, K, H, W);
     return tocvp_launch_status();
 }
