@@ -810,8 +810,10 @@ static int ksplit_wgs() {
 static int pick_ksplit(const GemmArgs& p, int bk) {
     const int tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64), nk = p.K / bk, least = bk == 32 ? 4 : 2;
     int S = 1;
-    while (S < 16 && tiles * S * 2 <= ksplit_wgs() && nk % (S * 4) == 0 && nk / (S * 2) >= least) S *= 2;   // 1 .. 16
-    return (tiles <= 1024 && tiles * S <= WFRAG_WS_RECORDS) ? S : 1;
+    while (S < 16 && tiles * S * 2 <= ksplit_wgs() && tiles * S * 2 <= WFRAG_WS_RECORDS && nk % (S * 4) == 0 &&
+           nk / (S * 2) >= least)
+        S *= 2;                                                        // 1, 2, 4, 8, 16
+    return tiles <= 1024 ? S : 1;
 }
 // k-tile depth of the 64 x 64 kernel: 64 where it leaves an even number of k-tiles (the loop takes two per iteration),
 // else 32; TOCVP_GEMM_SMALL_BK=32 pins the shallow form.  Measured (scripts/ksplit_bench.py, graph replay, us):
@@ -868,6 +870,7 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
     }();
     if (variant == 1 && big_tiles >= 1024) return launch_wfrag<2, 256, 128, 64, 64, 8, 2, true>(p, s);
     if (variant == 2) return launch_wfrag<2, 128, 128, 64, 32, 8, 2, true>(p, s);
+    // (64-deep k-tiles in THIS kernel need 2 x 64 fragment registers: 256 VGPRs + 50 spilled, not built)
     return launch_wfrag<2, 128, 128, 64, 64, 4, 2, true>(p, s);
 }
 
