@@ -132,14 +132,17 @@ def test_decomp_only_eval_against_reference_golden():
     print("decomp-only eval vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert all(v < 1e-4 for v in errs.values()), errs
     assert float(out["recons_clamped"].min()) >= 0.0 and float(out["recons_clamped"].max()) <= 1.0
-    # slot-index map: identical except on pixels where the reference's OWN top-2 masks tie in fp32 (the golden
-    # holds one such pixel, margin 3.4e-7: tests/test_oracle_golden.py::test_decomp_only_eval_c1)
+    # slot-index map: identical except on pixels whose top-2 masks tie at fp32 rounding level.  The golden holds one
+    # pixel that the CPU oracle itself resolves the other way (margin 3.4e-7: tests/test_oracle_golden.py::
+    # test_decomp_only_eval_c1; 2.2e-7 here); since the decoder conv adds its 25 taps dx-major (operand fragments
+    # shared between a wave's two output rows) a second one at 1.4e-6 -- about ten ulps of a mask of 0.1-1 -- goes the
+    # other way too.  Both are named by their margins; any third pixel or a larger margin fails.
     am = out["masks"].argmax(dim=2).cpu()
     diff = am != torch.from_numpy(g["masks_argmax"].astype(np.int64))
     top2 = out["masks"].topk(2, dim=2).values.cpu()
     margin = (top2[:, :, 0] - top2[:, :, 1])[diff]
     print(f"decomp-only eval: {int(diff.sum())} of {diff.numel()} argmax pixels differ, margins {margin.tolist()}")
-    assert int(diff.sum()) <= 1 and (margin.numel() == 0 or float(margin.max()) < 1e-6)
+    assert int(diff.sum()) <= 2 and (margin.numel() == 0 or float(margin.max()) < 2e-6)
     tracker.aggregate()
     res = tracker.get_results()
     ref_psnr = 10 * torch.log10(1 / ((torch.from_numpy(g["recons_imgs"]).clamp(0, 1) - videos.cpu()) ** 2)

@@ -527,14 +527,17 @@ def test_conv5x5_dec_f16x3_is_fp32_class(n):
     assert err[1].max().item() < 3e-6                    # relative accuracy at the small image's own scale
     got_lin = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=False)
     assert (got_lin.cpu().double() - lin).abs().max().item() < max(2.5 * err32, 2e-6 * lin.abs().max().item())
-    # the persistent and the two-workgroups-per-CU forms of the kernel run the same arithmetic in the same order
+    # the persistent form of the kernel (off by default) runs the same products; since the default form shares operand
+    # fragments between a wave's two output rows it adds the 25 taps dx-major, the persistent one dy-major: equal to
+    # fp32 rounding, and as close to fp64 as the default
     monkey = k._CONV_PERSISTENT
     try:
         k._CONV_PERSISTENT = not monkey
         other = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=True)
     finally:
         k._CONV_PERSISTENT = monkey
-    assert torch.equal(other, got)
+    assert (other - got).abs().max().item() < 2e-6 * scale
+    assert (other.cpu().double() - ref).abs().max().item() < max(2.5 * err32, 2e-6 * scale)
     # pass-major input / output: same values, other layout
     xpm = _to_pass_major(x).to(DEV)
     for pm_in, pm_out in ((True, False), (False, True), (True, True)):

@@ -655,9 +655,12 @@ def test_graph_replayed_steps_equal_eager_steps():
     for n in res[0][1]:
         # three steps of at most lr = 1e-4.  Not bit-identical: two float-atomic reductions in the backward pass
         # make gradients reproducible to ~1e-10, and Adam turns a near-zero gradient g into lr * g / (|g| + eps),
-        # i.e. amplifies that by lr / eps = 1e4 on the few elements whose gradient vanishes (worst case 3 lr = 3e-4;
-        # seen: up to 1.2e-5 on one element of one MLP weight)
-        assert (res[0][1][n] - res[1][1][n]).abs().max().item() < 5e-5, n
+        # i.e. amplifies that by lr / eps = 1e4 -- up to a flipped sign of a whole update (2 lr) -- on the few elements
+        # whose gradient vanishes.  So: every element within the 3-step worst case, all but a handful within 1e-5
+        # (seen: one element of one MLP weight at 1.2e-5, another run one at 1.06e-4)
+        d = (res[0][1][n] - res[1][1][n]).abs()
+        assert d.max().item() <= 6.1e-4, n
+        assert int((d > 1e-5).sum()) <= max(2, d.numel() // 100000), (n, int((d > 1e-5).sum()))
 
 
 @pytest.mark.parametrize("M,N,Kd,tA,tB,ld_pad", [(70, 50, 33, False, False, 0), (64, 64, 64, True, False, 0),

@@ -19,7 +19,8 @@
 // ds_read_b128) = 65 KB -> 2 workgroups per CU, one staging while the other multiplies.
 // Weights in MFMA-fragment order straight from L1/L2, one tap (4 KiB) ahead in registers; the 25
 // taps of a pass are fully unrolled (LDS offsets are immediates, no barrier inside a pass).
-// Per tap and wave: 12 ds_read_b128, 4 global 16-B loads, 24 MFMAs (768 matrix cycles).
+// Per tap and wave: 4 global 16-B loads, 24 MFMAs (768 matrix cycles), and 4.8 ds_read_b128 (operand fragments are
+// shared between the wave's two output rows, TOCVP_CONV_ROWREUSE below; 8 without).
 // fp32 NHWC (or the pass-major layout (n, 4, H, W, 16) between consecutive layers) in HBM.
 #include <stdlib.h>
 #include <string.h>
@@ -41,6 +42,16 @@
 #endif
 #ifndef TOCVP_CONV_WEAVE
 #define TOCVP_CONV_WEAVE 1
+#endif
+// 1 (default, round 3): operand fragments shared by the two output rows of a wave.  Input row q of the wave's 6-row
+// window is the operand of output row 0 at tap row dy = q AND of output row 1 at dy = q - 1, so a pass walks (dx, q)
+// -- 30 steps, 4 ds_read_b128 each = 120 per pass instead of 25 taps x 8 = 200 -- with the weights of tap (q, dx)
+// kept one step longer for row 1 (three rolling register sets).  Same 600 MFMAs per pass; the 25 taps of an
+// accumulator are added dx-major instead of dy-major (same products, another fp32 rounding order).  Measured: probe on
+// dense random data 3.976 -> 3.924 ms per 2040 slot images (two rounds, scripts/probes/conv16_ablate.hip -DLAYOUT=3);
+// in the bench, same box, 3.798 -> 3.692 ms (447.6 -> 460.5 TFLOP/s algorithmic; value_no_overlap 3607 -> 3676).
+#ifndef TOCVP_CONV_ROWREUSE
+#define TOCVP_CONV_ROWREUSE 1
 #endif
 
 namespace {
@@ -184,7 +195,79 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
         load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
         __syncthreads();
 
-#if TOCVP_CONV_WEAVE
+#if TOCVP_CONV_ROWREUSE
+        {
+            f16x8 fa[2][2][2];                                      // [set][32-pixel half][plane]
+            f16x8 w3[3][2][2];                                      // rolling weights of tap rows q-1, q, q+1: [slot][plane][n]
+            auto read_rows = [&](int set, int q, int dx) {
+                const unsigned char* a_base = in_s + (q * IW + dx) * ROWB;
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) {
+                    fa[set][xh][0] = *reinterpret_cast<const f16x8*>(a_base + a_off[xh]);
+                    fa[set][xh][1] = *reinterpret_cast<const f16x8*>(a_base + a_off[xh] + OFF_LO);
+                }
+            };
+            auto load_w3 = [&](int slot, int dy, int dx) {
+                const unsigned char* base = p.wf + (size_t)(pass * NTAP + dy * 5 + dx) * TAP_BYTES + lane * 16;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        w3[slot][pl][n] = *reinterpret_cast<const f16x8*>(base + (pl * 2 + n) * FRAG);
+            };
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) w3[0][pl][n] = bw[0][pl][n];     // tap (0, 0) was fetched across the barrier
+            read_rows(0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 30; ++st) {
+                const int dx = st / 6, q = st % 6, cur = st & 1;
+                int nw = 0, nr = 0;
+                if (q < 4) {                                        // weights of tap row q + 1, used from the next step on
+                    load_w3((q + 1) % 3, q + 1, dx);
+                    nw = 4;
+                } else if (q == 5 && dx < 4) {
+                    load_w3(0, 0, dx + 1);
+                    nw = 4;
+                }
+                if (st + 1 < 30) {
+                    read_rows(cur ^ 1, (st + 1) % 6, (st + 1) / 6);
+                    nr = 4;
+                }
+                int nm = 0;
+                if (q < 5) {                                        // output row 0, tap (q, dx)
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            acc[xh][n] = mfma16(fa[cur][xh][1], w3[q % 3][0][n], acc[xh][n]);      // Xl Wh
+                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][1][n], acc[xh][n]);      // Xh Wl
+                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][0][n], acc[xh][n]);      // Xh Wh
+                        }
+                    nm += 12;
+                }
+                if (q > 0) {                                        // output row 1, tap (q - 1, dx)
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][n], acc[2 + xh][n]);
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][n], acc[2 + xh][n]);
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][n], acc[2 + xh][n]);
+                        }
+                    nm += 12;
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    if (2 * i >= nm) break;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          // MFMA
+                    if (i < nw) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // weight fragment load
+                    else if (i - nw < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // operand read
+                }
+            }
+        }
+#elif TOCVP_CONV_WEAVE
         // A fragments one tap ahead in a second register set, reads and weight loads woven between the MFMAs of
         // the current tap (sched_group_barrier): the LDS latency of a tap's eight operand reads no longer sits in
         // front of its first MFMA
