@@ -1,0 +1,33 @@
+"""Determinism stress of the split-K skinny GEMM: every shape is run many times, interleaved with other shapes that
+reuse the same workspace records, with and without residual / activation; every repetition must equal the first."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from textocvp_amd import kernels as k
+dev = torch.device("cuda", 0)
+random.seed(0); torch.manual_seed(0)
+shapes = []
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    shapes.append((random.choice([1, 7, 30, 60, 64, 65, 128, 150, 210, 300, 301, 448, 600, 1200]),
+                   random.choice([128, 384, 512, 1536, 2048]), random.choice([128, 256, 512, 1024, 2048])))
+data = {}
+for (M, N, K) in set(shapes):
+    data[(M, N, K)] = (torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev),
+                       torch.randn(M, N, device=dev))
+first, bad = {}, 0
+for rep in range(30):
+    order = list(set(shapes)); random.shuffle(order)
+    for s in order:
+        x, w, b, r = data[s]
+        y = k.linear(x, w, b, act=k.ACT_RELU, residual=r, precision="f16x3")
+        if s not in first:
+            first[s] = y.clone()
+            ref = torch.relu(x.double() @ w.double().t() + b.double()) + r.double()
+            err = (y.double() - ref).abs().max().item()
+            assert err < 1e-4 * ref.abs().max().item(), (s, err)
+        elif not torch.equal(y, first[s]):
+            d = (y - first[s]).abs()
+            bad += 1
+            print("MISMATCH", s, "rep", rep, "max", d.max().item(), "count", int((d > 0).sum()), flush=True)
+torch.cuda.synchronize()
+print("shapes", len(set(shapes)), "mismatches", bad)

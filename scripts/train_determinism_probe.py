@@ -1,0 +1,21 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+import torch
+import test_train_gpu as T
+DEV = "cuda"
+def run(graphed):
+    ts, videos, tokens, lengths, noise = T._build_step()
+    args = (videos.to(DEV), tokens.to(DEV), lengths.to(DEV))
+    f = ts.step_graphed if graphed else ts.step
+    losses = [f(*args, init_noise=noise.to(DEV)) for _ in range(3)]
+    l = [float(x["loss"]) for x in losses]
+    return l, {n: v.data.detach().cpu().clone() for n, v in ts.model.names.items()}
+def cmp(a, b, tag):
+    worst = max(((a[1][n] - b[1][n]).abs().max().item(), n) for n in a[1])
+    cnt = sum(int(((a[1][n] - b[1][n]).abs() > 1e-5).sum()) for n in a[1])
+    print(tag, "losses", a[0], b[0], "worst", worst, "count>1e-5", cnt, flush=True)
+e1, e2 = run(False), run(False)
+cmp(e1, e2, "eager-eager")
+g1, g2 = run(True), run(True)
+cmp(g1, g2, "graph-graph")
+cmp(e1, g1, "eager-graph")

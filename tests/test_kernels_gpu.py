@@ -546,6 +546,48 @@ def test_conv5x5_dec_f16x3_is_fp32_class(n):
         assert torch.equal(y.cpu(), want), (pm_in, pm_out)
 
 
+@pytest.mark.parametrize("n", [3, 21])
+def test_conv5x5_dec_f16x3_operand_planes_between_layers(n):
+    """ two layers chained through fp16 operand planes (producer epilogue writes [Xh | Xl] per pixel and pass, the
+    consumer stages them by LDS-DMA) == the same layers chained through fp32 pass-major buffers, bit for bit, and a
+    three-layer chain planes -> planes -> NHWC as the decoder runs it; image borders, saturating values and exact
+    zeros included """
+    k = _k()
+    x = rnd("px", (n, 64, 64, 64))
+    x[0, :4, :4] = 0.0
+    x[0, 5, 5, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 1e-3, 40.0, -90.0, 200.0, 0.25])
+    x[1] = x[1] * 1e-3
+    ws = [rnd(f"pw{i}", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5) for i in range(3)]
+    ws[0] *= 40.0                                         # drives some layer-1 outputs past the fp16-plane range (255)
+    bs = [rnd(f"pb{i}", (64,), "uniform", 0.1) for i in range(3)]
+    wf = [k.split_conv_weights_dec_f16x3(w.to(DEV)) for w in ws]
+    bd = [b.to(DEV) for b in bs]
+    xd = x.to(DEV)
+
+    def chain(planes):
+        y1 = k.conv5x5_dec_f16x3(xd, wf[0], bd[0], relu=True, pm_out=True, planes=planes)
+        y2 = k.conv5x5_dec_f16x3(y1, wf[1], bd[1], relu=True, pm_in=True, pm_out=True, planes=planes)
+        return y1, k.conv5x5_dec_f16x3(y2, wf[2], bd[2], relu=True, pm_in=True, planes=planes)
+
+    y1_f, y3_f = chain(False)
+    y1_p, y3_p = chain(True)
+    assert torch.equal(y3_p, y3_f)
+    assert float(y1_f.max()) > 255.0                     # the saturating case is really in the data
+    # the planes buffer itself: hi + lo of 2^8 y, saturated at the fp16 range, per pixel and pass
+    pl = y1_p.view(torch.float16).view(n, 4, 64, 64, 2, 16).float()
+    want = (y1_f.view(n, 4, 64, 64, 16) * 256.0).clamp(-65504.0, 65504.0)
+    assert (pl.sum(4) - want).abs().max().item() <= 2.0 ** -10 * 256.0 * 255.0 * 2.0 ** -11
+    # against fp64 through all three layers (inputs of layer 2 / 3 saturate where layer 1 exceeded the range, so the
+    # reference clamps the same way)
+    ref = x.double()
+    for li, (w, b) in enumerate(zip(ws, bs)):
+        ref = torch.relu(F.conv2d(ref.permute(0, 3, 1, 2), w.double(), b.double(), padding=2).permute(0, 2, 3, 1))
+        if li < 2:
+            ref = ref.clamp(max=65504.0 / 256.0)
+    got = y3_p.cpu().double()
+    assert (got - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
 def test_conv5x5_dec_f16x3_collapsed_input_and_range():
     """ layer-1 mode of the default decoder conv + the weight range check at split time """
     k = _k()

@@ -653,14 +653,16 @@ def test_graph_replayed_steps_equal_eager_steps():
         assert a["lr"] == b["lr"]
     assert res[0][0][0]["loss"] != res[0][0][2]["loss"]                       # the weights really moved
     for n in res[0][1]:
-        # three steps of at most lr = 1e-4.  Not bit-identical: two float-atomic reductions in the backward pass
-        # make gradients reproducible to ~1e-10, and Adam turns a near-zero gradient g into lr * g / (|g| + eps),
-        # i.e. amplifies that by lr / eps = 1e4 -- up to a flipped sign of a whole update (2 lr) -- on the few elements
-        # whose gradient vanishes.  So: every element within the 3-step worst case, all but a handful within 1e-5
-        # (seen: one element of one MLP weight at 1.2e-5, another run one at 1.06e-4)
+        # three steps of at most lr = 1e-4.  Not bit-identical: two float-atomic reductions in the backward pass make
+        # gradients reproducible to ~1e-10, and two things amplify that: Adam turns a near-zero gradient g into
+        # lr * g / (|g| + eps) (lr / eps = 1e4, up to a flipped sign of a whole update), and a hidden unit whose
+        # pre-activation sits within that noise of zero is switched on in one run and off in the other -- then its whole
+        # weight row (512 elements) moves by +-lr per step.  scripts/train_determinism_probe.py shows the same two
+        # outcomes between two EAGER runs (and between two replayed ones): it is the step, not the replay.  So: every
+        # element within the 3-step worst case, all but 0.1 % of a tensor within 1e-5
         d = (res[0][1][n] - res[1][1][n]).abs()
         assert d.max().item() <= 6.1e-4, n
-        assert int((d > 1e-5).sum()) <= max(2, d.numel() // 100000), (n, int((d > 1e-5).sum()))
+        assert int((d > 1e-5).sum()) <= max(2, d.numel() // 1000), (n, int((d > 1e-5).sum()))
 
 
 @pytest.mark.parametrize("M,N,Kd,tA,tB,ld_pad", [(70, 50, 33, False, False, 0), (64, 64, 64, True, False, 0),

@@ -72,7 +72,9 @@ constexpr int TAP_BYTES = 4 * FRAG;           // [plane(h, l)][nb(2)]
 struct Args {
     const float* x; const float* aux; const unsigned char* wf; const float* bias; float* y;
     int nimg, H, W, relu;
-    int pm_in, pm_out;      // pass-major activation layout (n, 4, H, W, 16) instead of NHWC (n, H, W, 64)
+    int pm_in, pm_out;      // pass-major activation layout (n, 4, H, W, 16) instead of NHWC (n, H, W, 64);
+                            // pm_out == 2 (and the PLANES_IN kernel): the 64 bytes of a pixel and pass hold the
+                            // operand planes [16 f16 Xh | 16 f16 Xl] of 2^8 x instead of 16 floats
 };
 
 __device__ __forceinline__ int border_class(int p, int n) {
@@ -85,12 +87,25 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <int MODE>
+// PLANES_IN (layers 2 and 3 behind a planes-writing layer): the halo tile is NOT converted here.  The producer's
+// epilogue wrote, per pixel and 16-channel pass, the 64 bytes [Xh | Xl] this kernel's staging would compute from its
+// fp32 output (same arithmetic: bit-identical results); they go global -> LDS by DMA (global_load_lds, 16 bytes per
+// lane): the image is 4080 chunks of 16 bytes (816 pixels x [Xh 0-7 | Xh 8-15 | Xl 0-7 | Xl 8-15 | pad]), thread t
+// moves chunks t, t + 256, ... with source offsets computed once per tile -- no staging registers, no conversion
+// instructions, no ds_write; pixels outside the image are loaded from a clamped address and zeroed afterwards.
+template <int MODE, bool PLANES_IN = false>
 __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
     constexpr int NT = 256;
     constexpr int SS = C + 4;                                       // padded floats per staged pixel
     constexpr int STAGE_BYTES = 4 * 64 * SS * 4;                    // one 64-pixel row per wave
-    constexpr int LDS_BYTES = IH * IW * ROWB > STAGE_BYTES ? IH * IW * ROWB : STAGE_BYTES;
+    constexpr int NCHUNK = IH * IW * 5, NDMA = (NCHUNK + NT - 1) / NT;   // 4080 chunks, 16 DMA instructions per thread
+    constexpr int IMG_BYTES = PLANES_IN ? NDMA * NT * 16 : IH * IW * ROWB;
+    constexpr int WORK_BYTES = IMG_BYTES > STAGE_BYTES ? IMG_BYTES : STAGE_BYTES;
+    // PLANES_IN: the 16 source offsets of a thread (16-byte units inside a pass plane, < 2^16) wait in LDS between
+    // the passes -- in registers they would sit next to the 128 accumulators through every MFMA loop (spills)
+    constexpr int LDS_BYTES = WORK_BYTES + (PLANES_IN ? NT * 32 : 0);
+    static_assert(NDMA == 16, "two 16-byte records of eight 16-bit offsets per thread");
+    static_assert(!(PLANES_IN && MODE != 0), "the collapsed layer synthesises its input");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* in_s = lds;
 
@@ -136,8 +151,45 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                 bw[set][pl][n] = *reinterpret_cast<const f16x8*>(base + (pl * 2 + n) * FRAG);
     };
 
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8* const my_offs = reinterpret_cast<u16x8*>(lds + WORK_BYTES) + 2 * t;
+    unsigned outside = 0;                       // bit i: chunk i of this thread lies outside the image (zeroed after the DMA)
+    if (PLANES_IN) {
+        u16x8 o[2];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int g = i * NT + t, gc = min(g, NCHUNK - 1);
+            const int pix = gc / 5, j = gc % 5;
+            const int iy = ty0 + pix / IW - 2, ix = tx0 + pix % IW - 2;
+            const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+            o[i >> 3][i & 7] = (unsigned short)((iyc * p.W + ixc) * 4 + (j & 3));
+            if (!inside && j < 4 && g < NCHUNK) outside |= 1u << i;
+        }
+        my_offs[0] = o[0];
+        my_offs[1] = o[1];                       // read back by this thread only: no barrier needed
+    }
+
     for (int pass = 0; pass < NPASS; ++pass) {
         if (pass > 0) __syncthreads();          // every wave is done reading the previous image
+        if (PLANES_IN) {
+            const char* pbase = xbase + (size_t)pass * p.H * p.W * 64;                  // uniform
+            const u16x8 o0 = my_offs[0], o1 = my_offs[1];
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(pbase + (unsigned)(i < 8 ? o0[i & 7] : o1[i & 7]) * 16u),
+                    (__attribute__((address_space(3))) void*)(in_s + (i * 4 + wave) * 1024), 16, 0, 0);
+            load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (outside) {
+#pragma unroll
+                for (int i = 0; i < NDMA; ++i)
+                    if ((outside >> i) & 1u)
+                        *reinterpret_cast<f32x4*>(in_s + (i * NT + t) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        } else {
         // ---- halo tile: fp32 -> (Xh | Xl) fp16 planes in LDS.  All global loads of a batch are issued
         // back to back from clamped (always valid) addresses and only then converted.  An opaque copy of
         // the thread index keeps the staging addresses per-pass temporaries (hoisted out of the pass
@@ -194,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
         }
         load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
         __syncthreads();
+        }
 
 #if TOCVP_CONV_ROWREUSE
         {
@@ -350,7 +403,25 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
         }
         __builtin_amdgcn_wave_barrier();
         const int oy = ty0 + 2 * wave + r2;
-        if (p.pm_out) {
+        if (p.pm_out == 2) {
+            // operand planes for the next layer: exactly the split its own staging would make of these values
+            unsigned char* ybase = reinterpret_cast<unsigned char*>(p.y + (size_t)img * p.H * p.W * C);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int plane = it >> 2, px = (it & 3) * 16 + (lane >> 2), cq = (lane & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
+                f16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float X = clampf(v[u] * SA, F16MAX);
+                    hi[u] = (_Float16)X;
+                    lo[u] = (_Float16)(X - (float)hi[u]);
+                }
+                unsigned char* blk = ybase + (((size_t)plane * p.H + oy) * p.W + tx0 + px) * 64 + cq * 2;
+                *reinterpret_cast<f16x4*>(blk) = hi;
+                *reinterpret_cast<f16x4*>(blk + OFF_LO) = lo;
+            }
+        } else if (p.pm_out) {
             float* ybase = p.y + (size_t)img * p.H * p.W * C;
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -656,7 +727,10 @@ extern "C" int tocvp_split_conv_weights_dec_f16x3(const float* w, void* wf, int 
 extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf,
                                            const float* bias, float* y, int nimg, int H, int W, int Cin,
                                            int Cout, int relu, int layout, void* stream) {
-    TOCVP_CHECK_ARG(layout >= 0 && layout <= 7 && !(in_mode == 1 && (layout & 1)));
+    // layout: bit 0 pass-major input, bit 1 pass-major output, bit 2 persistent form, bit 3 the pass-major buffers hold
+    // operand planes (written by / read from a neighbouring layer of this kernel; not with the persistent form)
+    TOCVP_CHECK_ARG(layout >= 0 && layout <= 15 && !(in_mode == 1 && (layout & 1)));
+    TOCVP_CHECK_ARG(!(layout & 8) || ((layout & 3) != 0 && !(layout & 4)));
     TOCVP_CHECK_ARG(x && wf && bias && y);
     TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
     TOCVP_CHECK_ARG(Cin == C && Cout == C);
@@ -668,7 +742,7 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
         return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     Args a{x, aux, static_cast<const unsigned char*>(wf), bias, y, nimg, H, W, relu, layout & 1,
-           (layout >> 1) & 1};
+           (layout & 2) ? ((layout & 8) ? 2 : 1) : 0};
     const int ntiles = (int)((size_t)nimg * (H / TH) * (W / TW));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (layout & 4) {
@@ -694,9 +768,11 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
 #else
     const dim3 grid((unsigned)ntiles);
 #endif
-    if (in_mode == 0)
-        hipLaunchKernelGGL(conv5x5_dec_f16x3_kernel<0>, grid, dim3(256), 0, s, a);
+    if (in_mode == 0 && (layout & 9) == 9)
+        hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<0, true>), grid, dim3(256), 0, s, a);
+    else if (in_mode == 0)
+        hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<0, false>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(conv5x5_dec_f16x3_kernel<1>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<1, false>), grid, dim3(256), 0, s, a);
     return tocvp_launch_status();
 }

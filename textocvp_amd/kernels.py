@@ -1027,11 +1027,16 @@ def split_conv_weights_dec_f16x3(w):
 _CONV_PERSISTENT = os.environ.get("TOCVP_CONV_PERSISTENT", "0") != "0"
 
 
-def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False):
+def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False, planes=False):
     """
     64->64 5x5 conv with split-fp16 operands (tocvp_conv5x5_dec_f16x3_f32, fp32-class), fp32 in/out.
     wf = split_conv_weights_dec_f16x3(weight); collapsed / pm_in / pm_out as conv5x5_f16f8.
+    planes: the pass-major buffers (pm_in / pm_out) hold the fp16 operand planes [Xh | Xl] per pixel and pass instead
+    of 16 floats -- written by the producing layer's epilogue, moved into LDS by DMA in the consuming layer; same
+    bytes, bit-identical results.  Never with the range check on (the planes cannot be inspected as fp32).
     """
+    # (producer and consumer of a buffer are called with the same flag and see the same two switches)
+    planes = bool(planes) and bool(pm_in or pm_out) and not _CHECK_RANGE and not _CONV_PERSISTENT
     if collapsed is not None:
         cpos, S = collapsed
         H, W, Cin = cpos.shape
@@ -1054,7 +1059,7 @@ def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=Fa
         _check(lib().tocvp_conv5x5_dec_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf), _ptr(bias), _ptr(out),
                                                  n, H, W, Cin, Cout, int(bool(relu)),
                                                  int(bool(pm_in)) | (int(bool(pm_out)) << 1) |
-                                                 (4 if _CONV_PERSISTENT else 0), _stream()),
+                                                 (4 if _CONV_PERSISTENT else 0) | (8 if planes else 0), _stream()),
                "tocvp_conv5x5_dec_f16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)

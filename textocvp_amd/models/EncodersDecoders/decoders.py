@@ -72,6 +72,8 @@ class ConvDecoder(nn.Module):
         #            product): fastest, but beyond 1e-4 on recons / masks for un-damped heads -> opt-in.
         self.conv_precision = knob("TOCVP_DECODER_PRECISION", "f16x3")
         self.pass_major = os.environ.get("TOCVP_CONV_PASS_MAJOR", "1") != "0"
+        # f16x3 layers hand their activations over as fp16 operand planes (the consumer stages them by LDS-DMA)
+        self.conv_planes = os.environ.get("TOCVP_CONV_PLANES", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
@@ -154,7 +156,7 @@ class ConvDecoder(nn.Module):
                     if self.conv_precision == "f16x3":
                         x = K.conv5x5_dec_f16x3(x, self._split16(i), conv.bias, relu=True, out=out,
                                                 collapsed=(cpos, S) if i == 1 else None,
-                                                pm_in=pm_prev, pm_out=pm_out)
+                                                pm_in=pm_prev, pm_out=pm_out, planes=self.conv_planes)
                     else:
                         x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
                                             collapsed=(cpos, S) if i == 1 else None,
