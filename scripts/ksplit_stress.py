@@ -6,7 +6,9 @@ import torch
 from textocvp_amd import kernels as k
 dev = torch.device("cuda", 0)
 random.seed(0); torch.manual_seed(0)
-shapes = []
+shapes = [(14, 128, 512), (14, 2048, 512), (14, 512, 128), (14, 512, 2048), (14, 512, 512), (24, 128, 128),
+          (24, 128, 512), (24, 384, 128), (24, 512, 128), (24, 512, 512), (28, 2048, 512), (28, 512, 128),
+          (28, 512, 2048), (28, 512, 512)]            # the training test's shapes (tiles not a multiple of 8: slices on several XCDs)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     shapes.append((random.choice([1, 7, 30, 60, 64, 65, 128, 150, 210, 300, 301, 448, 600, 1200]),
                    random.choice([128, 384, 512, 1536, 2048]), random.choice([128, 256, 512, 1024, 2048])))
@@ -15,7 +17,7 @@ for (M, N, K) in set(shapes):
     data[(M, N, K)] = (torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev),
                        torch.randn(M, N, device=dev))
 first, bad = {}, 0
-for rep in range(30):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     order = list(set(shapes)); random.shuffle(order)
     for s in order:
         x, w, b, r = data[s]

@@ -14,8 +14,10 @@ def cmp(a, b, tag):
     worst = max(((a[1][n] - b[1][n]).abs().max().item(), n) for n in a[1])
     cnt = sum(int(((a[1][n] - b[1][n]).abs() > 1e-5).sum()) for n in a[1])
     print(tag, "losses", a[0], b[0], "worst", worst, "count>1e-5", cnt, flush=True)
-e1, e2 = run(False), run(False)
-cmp(e1, e2, "eager-eager")
-g1, g2 = run(True), run(True)
-cmp(g1, g2, "graph-graph")
-cmp(e1, g1, "eager-graph")
+runs = [run(False) for _ in range(int(os.environ.get("PROBE_RUNS", "4")))]
+for i in range(1, len(runs)):
+    cmp(runs[0], runs[i], f"eager0-eager{i}")
+if os.environ.get("PROBE_GRAPH", "0") == "1":
+    g1, g2 = run(True), run(True)
+    cmp(g1, g2, "graph-graph")
+    cmp(runs[0], g1, "eager-graph")

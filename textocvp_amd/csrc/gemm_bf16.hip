@@ -43,6 +43,7 @@ struct GemmArgs {
     int ksplit;                  // split-K (wfrag 64 x 64 kernel, SK = true): grid.y slices of K, > 1 needs the workspace
     float* ws_part;              // [tile][slice] raw accumulator records (lane order), 16 KB each
     unsigned* ws_ctr;            // [tile] arrival counters, zero between launches (the last arriver re-arms its own)
+    int sk_fence;                // diagnostics (TOCVP_GEMM_KSPLIT_FENCE=1): agent release in front of the arrival count
 };
 
 // R operand of the epilogue: residual (added) or, for TOCVP_ACT_GATE, the tensor whose sign gates the output
@@ -468,6 +469,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         __syncthreads();
         unsigned* arrived = reinterpret_cast<unsigned*>(lds);          // the A images are dead
         if (t == 0) {
+            if (p.sk_fence) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             const unsigned old = __hip_atomic_fetch_add(p.ws_ctr + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)(S - 1)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -831,6 +836,11 @@ template <int BK>
 int launch_small_f16(const GemmArgs& p, hipStream_t s) {
     GemmArgs q = p;
     q.ksplit = p.ws_part ? pick_ksplit(p, BK) : 1;
+    static const int fence = []() {
+        const char* e = getenv("TOCVP_GEMM_KSPLIT_FENCE");
+        return e ? atoi(e) : 0;
+    }();
+    q.sk_fence = fence;
     const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64;
     hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<2, 64, 64, 32, 32, 4, 1, false, true, true, BK>),
                        dim3(ntm * ntn, q.ksplit), dim3(256), 0, s, q);
