@@ -291,7 +291,12 @@ int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const
  * fp32-class.  Replaces nn.Conv2d(64,64,5,padding=2)+ReLU of ConvDecoder (decoders.py:96-110).
  * Valid for |x| < 255 and |w| < 63 (operands saturate beyond).  in_mode / aux as tocvp_conv5x5_f32,
  * layout bits 0 / 1 as tocvp_conv5x5_f16f8_f32; bit 2 selects the persistent form of the kernel (one workgroup
- * per CU walks its tiles with the next halo staged behind the MFMAs of the current one; same results).
+ * per CU walks its tiles with the next halo staged behind the MFMAs of the current one; same results);
+ * bit 3 (with bit 0 and / or 1, not with bit 2): the pass-major buffers hold fp16 OPERAND PLANES -- per pixel and
+ * 16-channel pass the 64 bytes [16 f16 Xh | 16 f16 Xl] of 2^8 x instead of 16 floats.  A layer called with bits 1 + 3
+ * writes them from its epilogue (the split the next layer's staging would make of the same values), a layer called
+ * with bits 0 + 3 stages them into LDS by DMA without converting: the chain gives bit-identical results to the fp32
+ * hand-over.  Such a buffer is only meaningful as the input of this entry point.
  *   wf: fragment-order weight image written by tocvp_split_conv_weights_dec_f16x3, of
  *   tocvp_conv_weights_dec_f16x3_bytes() bytes.
  * ------------------------------------------------------------------------------------------- */
