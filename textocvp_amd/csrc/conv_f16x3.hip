@@ -50,6 +50,12 @@
 // accumulator are added dx-major instead of dy-major (same products, another fp32 rounding order).  Measured: probe on
 // dense random data 3.976 -> 3.924 ms per 2040 slot images (two rounds, scripts/probes/conv16_ablate.hip -DLAYOUT=3);
 // in the bench, same box, 3.798 -> 3.692 ms (447.6 -> 460.5 TFLOP/s algorithmic; value_no_overlap 3607 -> 3676).
+// 1: the six products of a pixel block are issued so that one operand stays the same between neighbours (Xl Wh0, Xl Wh1,
+// Xh Wl1, Xh Wl0, Xh Wh0, Xh Wh1: five operand changes instead of nine; same order per accumulator, bit-identical):
+// 4.055 / 4.061 -> 4.045 / 4.036 ms per 2040 slot images in the probe (+0.4 %, two rounds)
+#ifndef TOCVP_CONV_MFMA_ORDER
+#define TOCVP_CONV_MFMA_ORDER 1
+#endif
 #ifndef TOCVP_CONV_ROWREUSE
 #define TOCVP_CONV_ROWREUSE 1
 #endif
@@ -290,6 +296,17 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                 }
                 int nm = 0;
                 if (q < 5) {                                        // output row 0, tap (q, dx)
+#if TOCVP_CONV_MFMA_ORDER
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) {                // one operand stays put between neighbours
+                        acc[xh][0] = mfma16(fa[cur][xh][1], w3[q % 3][0][0], acc[xh][0]);      // Xl Wh0
+                        acc[xh][1] = mfma16(fa[cur][xh][1], w3[q % 3][0][1], acc[xh][1]);      // Xl Wh1
+                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[q % 3][1][1], acc[xh][1]);      // Xh Wl1
+                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[q % 3][1][0], acc[xh][0]);      // Xh Wl0
+                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[q % 3][0][0], acc[xh][0]);      // Xh Wh0
+                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[q % 3][0][1], acc[xh][1]);      // Xh Wh1
+                    }
+#else
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
@@ -298,9 +315,21 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                             acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][1][n], acc[xh][n]);      // Xh Wl
                             acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][0][n], acc[xh][n]);      // Xh Wh
                         }
+#endif
                     nm += 12;
                 }
                 if (q > 0) {                                        // output row 1, tap (q - 1, dx)
+#if TOCVP_CONV_MFMA_ORDER
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) {
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][0], acc[2 + xh][0]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][1], acc[2 + xh][1]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][1], acc[2 + xh][1]);
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][0], acc[2 + xh][0]);
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][0], acc[2 + xh][0]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][1], acc[2 + xh][1]);
+                    }
+#else
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
@@ -309,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                             acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][n], acc[2 + xh][n]);
                             acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][n], acc[2 + xh][n]);
                         }
+#endif
                     nm += 12;
                 }
 #pragma unroll
