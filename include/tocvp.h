@@ -437,6 +437,13 @@ int tocvp_bmm_f32(const float* A, int lda, long sA1, long sA2, int transA, const
  * (04_train_predictor.py:96-104). */
 int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c_part, float* bias_part,
                       int M, int N, int K, int splits, int accumulate, void* stream);
+/* The same contract on the bf16 matrix cores with split operands: every value as two bf16 planes (16 significant
+ * bits, fp32 exponent range), three products per algorithmic product (~2^-17 each) into fp32 accumulators; the tiles
+ * stay row-major in LDS and both fragments are hardware-transposed reads (ds_read_b64_tr_b16).  M % 32 == 0 (the chunk
+ * of a split is rounded up to 32 rows); bias sums are taken from the fp32 values (exact).  May be mixed with
+ * tocvp_gemm_tn_f32 on the same partial buffers. */
+int tocvp_gemm_tn_bf16x3_f32(const float* G, int ldg, const float* X, int ldx, float* c_part, float* bias_part,
+                             int M, int N, int K, int splits, int accumulate, void* stream);
 /* Backward of multi-head softmax attention, fused (scores / probabilities never reach HBM), exact fp32 MFMA:
  * q, o, d_o, dq (B, Tq, E); k, v, dk, dv (B, Tk, E); E = H * 64; o = the forward output; stats (B, H, Tq, 2) is
  * scratch (log-sum-exp and <dO, O> per query row); key_len (B) int32 or NULL masks keys >= key_len[b] (their

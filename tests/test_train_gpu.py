@@ -28,14 +28,19 @@ def _ag():
     return autograd
 
 
-@pytest.mark.parametrize("rows", [112, 1600])
-def test_linear_backward_transpose_free_weight_gradient(rows):
-    """ N, K multiples of 128 and M % 16 == 0: dW and db come from tocvp_gemm_tn_f32 (split-K partial sums
-    kept per weight, every use of the weight inside one backward pass accumulates into them; the splits
-    are added once when the tape finishes).  Two uses with different row counts, then a second pass. """
+@pytest.mark.parametrize("rows,wgrad", [(112, "fp32"), (1600, "fp32"), (1600, "bf16x3"), (112, "bf16x3")])
+def test_linear_backward_transpose_free_weight_gradient(rows, wgrad, monkeypatch):
+    """ N, K multiples of 128 and M % 16 == 0: dW and db come from tocvp_gemm_tn_f32 / tocvp_gemm_tn_bf16x3_f32 (split-K
+    partial sums kept per weight, every use of the weight inside one backward pass accumulates into them; the splits
+    are added once when the tape finishes).  Two uses with different row counts, then a second pass.  The split-bf16
+    kernel (three products of two bf16 planes, M % 32 == 0 -- 336 rows fall back to fp32) is held to 16-bit-mantissa
+    accuracy, the exact fp32 MFMA to 1e-5. """
     ag = _ag()
     from textocvp_amd import kernels as K
     assert ag._TN
+    monkeypatch.setattr(ag, "_WGRAD_PRECISION", wgrad)
+    monkeypatch.setattr(ag, "_DGRAD_PRECISION", "bf16x6")
+    wtol = 1e-5 if wgrad == "fp32" or rows == 112 else 2e-5
     N, Kd = 256, 384
     w, b = rnd("tw", (N, Kd), "uniform", Kd ** -0.5), rnd("tb", (N,), "uniform", 0.1)
     xs = [rnd("tx0", (3, rows, Kd)), rnd("tx1", (1, 48, 2, Kd))]
@@ -52,7 +57,8 @@ def test_linear_backward_transpose_free_weight_gradient(rows):
         for Y, g in zip(Ys, gs):
             Y.grad = g.to(DEV)
         tape.backward()
-        assert rel_err(W.grad, rep * wr.grad) < 1e-5 and rel_err(B.grad, rep * br.grad) < 1e-5
+        print(f"weight gradient ({wgrad}, {rows} rows): rel err {rel_err(W.grad, rep * wr.grad):.2e}")
+        assert rel_err(W.grad, rep * wr.grad) < wtol and rel_err(B.grad, rep * br.grad) < 1e-5
         for X, xr in zip(Xs, xrs):
             assert rel_err(X.grad, xr.grad) < 1e-5
     # deterministic: the same tape twice gives the same bits

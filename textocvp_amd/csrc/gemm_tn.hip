@@ -133,6 +133,151 @@ __global__ __launch_bounds__(256, TN_STAGES == 3 ? 3 : 2) void gemm_tn_f32_kerne
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix cores with SPLIT operands (round 3): every fp32 value is two bf16 planes
+// (x = hi + lo, 16 significant bits, the fp32 exponent range -- gradients need no scale), the product
+// hi*lo + lo*hi + hi*hi by three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator (~2^-17 per product, the
+// arithmetic the data-gradient GEMMs use).  Both operands are reduced over their ROW index, i.e. the MFMA wants 8
+// consecutive token rows of ONE column per lane: the tiles stay row-major in LDS ([32 token rows][128 columns] per
+// plane, split while staged through registers) and both fragments are hardware-transposed reads (ds_read_b64_tr_b16;
+// rows 320 bytes apart so that the four rows of a read tile the 64 banks).  128 x 128 output tile per 4-wave
+// workgroup, 32 token rows per stage, two stages (80 KB: two workgroups per CU), the next stage's global loads in
+// flight under the current stage's 24 MFMAs per wave.  Same split-K / accumulate / bias contract as the fp32 kernel;
+// the bias sums are taken from the fp32 values in the staging registers (exact).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tn_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short tn_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int TB_ROWS = 32, TB_RS = 320, TB_PLANE = TB_ROWS * TB_RS, TB_OPER = 2 * TB_PLANE, TB_STAGE = 2 * TB_OPER;
+
+__device__ __forceinline__ tn_bf16x8 tn_tr_frag(const unsigned char* addr) {
+    typedef __attribute__((address_space(3))) tn_s16x4* lp;
+    union { tn_s16x4 s[2]; tn_bf16x8 b; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(addr));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(addr + 4 * TB_RS));
+    return u.b;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TB_STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int k0 = blockIdx.x * TN_T, n0 = blockIdx.y * TN_T, z = blockIdx.z;
+    const int r_lo = min(p.M, z * p.chunk), r_hi = min(p.M, r_lo + p.chunk);
+    const int nit = (r_hi - r_lo) / TB_ROWS;
+    if (nit == 0 && p.accumulate) return;          // nothing to add (workgroup-uniform)
+
+    // staging: thread t moves rows sr, sr + 8, sr + 16, sr + 24 of the stage, columns sc .. sc + 3 of both operands
+    const int sr = t >> 5, sc = (t & 31) * 4;
+    const bool want_bias = p.bias != nullptr && blockIdx.x == 0;        // workgroup-uniform
+    f32x4 gq[4], xq[4];
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int it) {
+        const size_t row = (size_t)(r_lo + it * TB_ROWS + sr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gq[i] = *reinterpret_cast<const f32x4*>(p.G + (row + 8 * i) * p.ldg + n0 + sc);
+            xq[i] = *reinterpret_cast<const f32x4*>(p.X + (row + 8 * i) * p.ldx + k0 + sc);
+        }
+    };
+    auto split_store = [&](unsigned char* dst, const f32x4 v) {
+        tn_bf16x4 hi, lo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            hi[u] = (__bf16)v[u];
+            lo[u] = (__bf16)(v[u] - (float)hi[u]);
+        }
+        *reinterpret_cast<tn_bf16x4*>(dst) = hi;
+        *reinterpret_cast<tn_bf16x4*>(dst + TB_PLANE) = lo;
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* st = lds + buf * TB_STAGE + sr * TB_RS + sc * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            split_store(st + 8 * i * TB_RS, gq[i]);
+            split_store(st + TB_OPER + 8 * i * TB_RS, xq[i]);
+            if (want_bias) bs += gq[i];
+        }
+    };
+
+    float* C = p.C + (size_t)z * p.N * p.K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                acc[i][j][r] = p.accumulate ? C[(size_t)n * p.K + k] : 0.f;
+            }
+
+    // transposed-read address of this lane inside a 16-row k-step: the 16-lane group (lane >> 4) & 1 takes columns
+    // 16 .. 31 of the fragment, lane 4q + p of a group supplies row 8h + q, columns 4p .. 4p + 3
+    const int i16 = lane & 15, c16 = ((lane >> 4) & 1) * 16;
+    const int rd_off = (8 * h + (i16 >> 2)) * TB_RS + (c16 + 4 * (i16 & 3)) * 2;
+    auto compute = [&](int buf) {
+        const unsigned char* gs = lds + buf * TB_STAGE + rd_off + wy * 128;
+        const unsigned char* xs = lds + buf * TB_STAGE + TB_OPER + rd_off + wx * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            tn_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = tn_tr_frag(gs + kk * 16 * TB_RS + i * 64);
+                al[i] = tn_tr_frag(gs + kk * 16 * TB_RS + i * 64 + TB_PLANE);
+                bh[i] = tn_tr_frag(xs + kk * 16 * TB_RS + i * 64);
+                bl[i] = tn_tr_frag(xs + kk * 16 * TB_RS + i * 64 + TB_PLANE);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if (nit > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const bool more = it + 1 < nit;               // workgroup-uniform
+        if (more) gload(it + 1);
+        compute(it & 1);
+        if (more) lstore((it + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                C[(size_t)n * p.K + k] = acc[i][j][r];
+            }
+    if (want_bias) {                                  // 8 threads (sr = 0 .. 7) share the columns sc .. sc + 3
+        float* red = reinterpret_cast<float*>(lds);
+        *reinterpret_cast<f32x4*>(red + sr * 128 + sc) = bs;
+        __syncthreads();
+        if (t < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += red[q * 128 + t];
+            float* b = p.bias + (size_t)z * p.N + n0 + t;
+            *b = p.accumulate ? *b + v : v;
+        }
+    }
+}
+
 }  // namespace
 
 // `splits` may be smaller than the number of slices of the caller's buffer when it accumulates (few token
@@ -150,5 +295,23 @@ extern "C" int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ld
     TnArgs a{G, X, c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
     const dim3 grid(K / TN_T, N / TN_T, splits);
     hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return tocvp_launch_status();
+}
+
+// Same contract on split bf16 operands (two planes each, three products: ~2^-17 per product); M % 32 == 0, and the
+// chunk of a split is rounded up to 32 rows.
+extern "C" int tocvp_gemm_tn_bf16x3_f32(const float* G, int ldg, const float* X, int ldx, float* c_part,
+                                        float* bias_part, int M, int N, int K, int splits, int accumulate,
+                                        void* stream) {
+    TOCVP_CHECK_ARG(G && X && c_part);
+    TOCVP_CHECK_ARG(M > 0 && M % TB_ROWS == 0 && N > 0 && N % TN_T == 0 && K > 0 && K % TN_T == 0);
+    TOCVP_CHECK_ARG(ldg >= N && ldx >= K && ldg % 4 == 0 && ldx % 4 == 0);
+    TOCVP_CHECK_ARG(tocvp_aligned16(G) && tocvp_aligned16(X));
+    TOCVP_CHECK_ARG(splits >= 1 && splits <= 65535);
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TB_ROWS - 1) / TB_ROWS * TB_ROWS;
+    TnArgs a{G, X, c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
+    const dim3 grid(K / TN_T, N / TN_T, splits);
+    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return tocvp_launch_status();
 }

@@ -36,6 +36,9 @@ _FUSED_ATTN_BWD = os.environ.get("TOCVP_TRAIN_FUSED_ATTN_BWD", "1") != "0"
 # the golden gradient norms (253 tensors at 2e-4) and losses (1e-5) of tests/golden/train_c5.npz hold, the step goes
 # from 581 to 554 ms at the configs[1] shapes (data-gradient GEMMs 85 -> ~55 ms).  TOCVP_TRAIN_DGRAD=bf16x6 restores six.
 _DGRAD_PRECISION = os.environ.get("TOCVP_TRAIN_DGRAD", "bf16x3")
+# weight gradients dW = g^T x of the large linears: "bf16x3" = the split-operand kernel (tocvp_gemm_tn_bf16x3_f32, the
+# arithmetic of the data gradients above) where the row count allows (M % 32 == 0), "fp32" = the exact fp32 MFMA
+_WGRAD_PRECISION = os.environ.get("TOCVP_TRAIN_WGRAD", "bf16x3")
 
 
 def _s():
@@ -181,9 +184,14 @@ def _weight_grad_tn(tape, W, b, g, x2):
             "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
     # later (accumulating) uses with few rows touch only as many slices as they can keep busy
     active = ent["splits"] if first else max(1, min(ent["splits"], M // 128))
-    K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
-        _L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
-                               active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32"))
+    if _WGRAD_PRECISION == "bf16x3" and M % 32 == 0:
+        K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
+            _L().tocvp_gemm_tn_bf16x3_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
+                                          active, 0 if first else 1, _s()), "tocvp_gemm_tn_bf16x3_f32"))
+    else:
+        K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
+            _L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
+                                   active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32"))
 
 
 def _finish_weight_grad(ent):
