@@ -292,9 +292,17 @@ def leg_train(dev, kernels, batch=32, steps=3):
     g = timer.summary().get("gemm_tn")
     if g and g["launches"]:
         tf = g["units"] / g["total_ms"] / 1e9
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_tn_f32_kernel (weight gradients dW = dY^T X, exact fp32 "
-                           "MFMA, split-K)", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+        from textocvp_amd.train import autograd as _ag
+        split = _ag._WGRAD_PRECISION == "bf16x3"
+        peak = 2500.0 if split else FP32_MFMA_PEAK_TFLOPS
+        res["roofline"] = {"bound": "mfma",
+                           "kernel": ("gemm_tn_bf16x3_kernel (weight gradients dW = dY^T X, split bf16 operands: 3 "
+                                      "matrix products per algorithmic product, transposed LDS reads, split-K; the few "
+                                      "launches whose row count is not a multiple of 32 run the exact-fp32 kernel)")
+                           if split else "gemm_tn_f32_kernel (weight gradients dW = dY^T X, exact fp32 MFMA, split-K)",
+                           "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                           "matrix_units_per_product": 3 if split else 1,
+                           "frac_executed_mfma": round((3 if split else 1) * tf / peak, 4),
                            "launches": g["launches"], "avg_launch_ms": round(g["total_ms"] / g["launches"], 4),
                            "ms_per_step": round(g["total_ms"], 1), "traffic": None,
                            "timed": "HIP events around every launch of the eager warm-up step of this run (graph "
