@@ -881,6 +881,10 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
     if (variant == 1 && big_tiles >= 1024) return launch_wfrag<2, 256, 128, 64, 64, 8, 2, true>(p, s);
     if (variant == 2) return launch_wfrag<2, 128, 128, 64, 32, 8, 2, true>(p, s);
     // (64-deep k-tiles in THIS kernel need 2 x 64 fragment registers: 256 VGPRs + 50 spilled, not built)
+    // Also measured at the end of round 3 on 38400 x 2048 x 512 / 38400 x 512 x 2048 (scripts/probes/gemm_ablate.hip,
+    // two rounds) and dropped: the four waves side by side along N (128 x 32 per wave: half the weight-fragment bytes on
+    // the vector-memory path, twice the LDS fragment reads) 391.8 / 348.5 -> 395.6 / 346.4 us; the split of the next A
+    // tile woven between the MFMAs of the current one with sched_group_barrier 380.6 / 341.2 -> 381.3-388.2 / 344.5-351.7.
     return launch_wfrag<2, 128, 128, 64, 64, 4, 2, true>(p, s);
 }
 
