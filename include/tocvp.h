@@ -134,6 +134,13 @@ int tocvp_gemm_f16wfrag_ws_f32(const void* A, int lda, const void* Wfrag, const 
  *   of every consumer removes the VALU work that bounded the in-kernel split. */
 
 /* ---------------------------------------------------------------------------------------------
+ * Range check of the fp16-plane arithmetic (the one checked pass after weights are loaded): `out` (one 32-bit word of
+ * device memory) receives the BIT PATTERN of max |x[i]| over n floats, NaN counted as +inf.  Replaces the
+ * torch abs / max reductions the check used to run.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_absmax_f32(const float* x, long n, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y[r,:] = LayerNorm(x[r,:] + add[r % add_rows,:]) * gamma + beta      (biased variance, eps)
  * Replaces nn.LayerNorm at attention.py:49-51,361-362,427,435-436, SAVi.py:116 and
  * text_encoders.py:63,65-68; `add` (may be NULL) fuses SoftPositionEmbed's addend

@@ -421,6 +421,22 @@ def test_gemm_f16x3_split_k_of_the_small_batches(M, N, K, monkeypatch):
     assert int(wk[:1024].view(torch.int32).abs().sum()) == 0
 
 
+def test_absmax_reduction_of_the_range_check():
+    """ tocvp_absmax_f32 (the reduction behind the checked pass): exact max |x| on odd sizes, strided views,
+    negative extremes, zeros; NaN reads as inf so that a check can never pass on it """
+    k = _k()
+    for n in (1, 63, 257, 100003, 4 * 1024 * 1024 + 5):
+        x = rnd(f"am{n}", (n,), "normal", 3.0)
+        x[n // 2] = -1234.5
+        assert k.absmax(x.to(DEV)) == 1234.5
+    y = rnd("am2d", (300, 96)).to(DEV)
+    assert k.absmax(y[:, 7:40]) == float(y[:, 7:40].abs().max())
+    assert k.absmax(torch.zeros(1000, device=DEV)) == 0.0
+    z = torch.ones(5000, device=DEV)
+    z[4321] = float("nan")
+    assert k.absmax(z) == float("inf")
+
+
 def test_gemm_f16x3_range_behaviour(monkeypatch):
     """ outside |x| < 255 the fp16 planes saturate: 11-bit accuracy up to 511, finite (never inf/nan)
     beyond; TOCVP_CHECK_RANGE turns the silent saturation into an error """

@@ -282,6 +282,23 @@ __global__ __launch_bounds__(256) void slot_init_kernel(const float* __restrict_
 
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
+// max |x| of a tensor as the BIT PATTERN of the (non-negative) float: orders like an unsigned integer, so one
+// atomicMax per wave collects it; a NaN anywhere reads as +inf (range checks must not pass on NaN)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        const unsigned b = v != v ? 0x7f800000u : (__float_as_uint(v) & 0x7fffffffu);
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 }  // namespace
 
 extern "C" int tocvp_version(void) { return TOCVP_VERSION; }
@@ -421,5 +438,17 @@ extern "C" int tocvp_embedding_f32(const int64_t* ids, const float* table, float
     if (rows == 0) return TOCVP_OK;
     hipLaunchKernelGGL(embedding_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ids, table, out, rows, D, vocab);
+    return tocvp_launch_status();
+}
+
+/* out (one 32-bit word) = bit pattern of max |x[i]| over n floats (NaN counts as +inf); the word is zeroed here. */
+extern "C" int tocvp_absmax_f32(const float* x, long n, void* out, void* stream) {
+    TOCVP_CHECK_ARG(x && out && n >= 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, 4, s) != hipSuccess) return TOCVP_ELAUNCH;
+    if (n == 0) return TOCVP_OK;
+    const long want = (n + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n,
+                       static_cast<unsigned*>(out));
     return tocvp_launch_status();
 }

@@ -8,6 +8,7 @@ library is missing or a call fails, this module raises.
 
 import ctypes
 import os
+import struct
 import weakref
 
 import torch
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "tocvp_gemm_f16planes_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_absmax_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_gemm_wfrag_ws_bytes": (ctypes.c_size_t, []),
     "tocvp_gemm_f16wfrag_ws_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -405,6 +407,15 @@ F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
 _CHECK_RANGE = os.environ.get("TOCVP_CHECK_RANGE", "0") != "0"
 
 
+def absmax(t):
+    """ max |t| of a device fp32 tensor on the library's own reduction (tocvp_absmax_f32); NaN reads as inf """
+    _dev_f32(t, "absmax operand")
+    tc = t if t.is_contiguous() else t.contiguous()
+    word = torch.empty(1, device=t.device, dtype=torch.int32)
+    _check(lib().tocvp_absmax_f32(_ptr(tc), tc.numel(), _ptr(word), _stream()), "tocvp_absmax_f32")
+    return struct.unpack("f", struct.pack("i", int(word.item())))[0]
+
+
 def _check_f16_range(amax, what, owner=None):
     """ checked pass (TOCVP_CHECK_RANGE=1 / check_range()): the fp16-plane arithmetic saturates at |x| = 255.9 """
     if not amax < F16X3_ACT_RANGE:                          # also trips on NaN
@@ -418,7 +429,7 @@ def _check_f16_weight_range(w, what):
     """ |w| < 63 for an fp16-plane weight image; skipped while a HIP graph is being captured (no sync there) """
     if torch.cuda.is_current_stream_capturing():
         return
-    wmax = float(w.abs().max())
+    wmax = absmax(w)
     if not wmax < F16X3_WEIGHT_RANGE:
         raise TocvpRangeError(
             f"{what} weight out of the fp16-plane range: |w| max {wmax:.4g} (< {F16X3_WEIGHT_RANGE}); "
@@ -556,7 +567,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         out = torch.empty((M, N), device=w.device, dtype=torch.float32)
     if frag_ok and nsplit == 22 and _CHECK_RANGE:
         if not pre_split:
-            _check_f16_range(float(x2.abs().max()), f"f16x3 GEMM ({M}x{N}x{K}) activation")
+            _check_f16_range(absmax(x2), f"f16x3 GEMM ({M}x{N}x{K}) activation")
         _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
     if (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
             M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
@@ -655,7 +666,7 @@ def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
     B, Tq, E = x.shape
     assert x.is_contiguous() and Gf.shape[0] == B * heads * 16 and Hf.shape[0] == B * E
     if _CHECK_RANGE:                               # |LayerNorm(x)| <= sqrt(E) max|gamma| + max|beta|
-        _check_f16_range(float(gamma.abs().max()) * E ** 0.5 + float(beta.abs().max()),
+        _check_f16_range(absmax(gamma) * E ** 0.5 + absmax(beta),
                          "collapsed cross-attention: bound of the LayerNorm output")
     y = torch.empty_like(x)
     _timed(f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * 16, lambda: _check(
@@ -699,7 +710,7 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
         return SplitAct(o, (B, Tq, E))
     o = torch.empty((B, Tq, E), device=q.device, dtype=torch.float32)
     if _ATTN_QK16 and _CHECK_RANGE:
-        _check_f16_range(max(float(q.abs().max()), float(k.abs().max()), float(v.abs().max())),
+        _check_f16_range(max(absmax(q), absmax(k), absmax(v)),
                          "attention q / k / v (f16x3 products)", owner=("kernels", "_ATTN_QK16"))
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
     _timed(f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, lambda: _check(
@@ -811,7 +822,7 @@ def conv5x5(x, wp, bias, relu=True, out=None, precision="fp32"):
         out = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
     split = precision == "f16x3" and Cin % 32 == 0 and Cout % 32 == 0 and H % 8 == 0
     if split and _CHECK_RANGE:
-        _check_f16_range(float(x.abs().max()), "conv5x5 (f16x3) input")
+        _check_f16_range(absmax(x), "conv5x5 (f16x3) input")
         _check_f16_weight_range(wp, "conv5x5 (f16x3)")
     def run():
         if split:
@@ -996,7 +1007,7 @@ def conv5x5_f16f8(x, wimgs, bias, relu=True, out=None, collapsed=None, pm_in=Fal
     wf16, wf8 = wimgs
     Cout = bias.shape[0]
     if _CHECK_RANGE:    # layer-1 mode: |relu(cpos + S[cls])| <= max|cpos| + max|S|
-        _check_f16_range(float(xin.abs().max()) + (float(aux.abs().max()) if mode == 1 else 0.0),
+        _check_f16_range(absmax(xin) + (absmax(aux) if mode == 1 else 0.0),
                          "conv5x5_f16f8 input")
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
@@ -1047,13 +1058,13 @@ def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=Fa
         assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
         xin, aux, mode, dev = cpos, S, 1, cpos.device
         if _CHECK_RANGE:    # |relu(cpos + S[cls])| <= max|cpos| + max|S|
-            _check_f16_range(float(cpos.abs().max()) + float(S.abs().max()), "conv5x5_dec_f16x3 layer-0 bound")
+            _check_f16_range(absmax(cpos) + absmax(S), "conv5x5_dec_f16x3 layer-0 bound")
     else:
         n, H, W, Cin = x.shape
         assert x.is_contiguous()
         xin, aux, mode, dev = x, None, 0, x.device
         if _CHECK_RANGE:
-            _check_f16_range(float(xin.abs().max()), "conv5x5_dec_f16x3 input")
+            _check_f16_range(absmax(xin), "conv5x5_dec_f16x3 input")
     Cout = bias.shape[0]
     if out is None:
         out = torch.empty((n, H, W, Cout), device=dev, dtype=torch.float32)
@@ -1098,7 +1109,7 @@ def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
     assert x.is_contiguous() and wp.shape[0] == 9 and wp.shape[2] == Cin
     y = torch.empty((n, H, W, Cout), device=x.device, dtype=torch.float32)
     if precision == "f16x3" and _CHECK_RANGE:
-        _check_f16_range(float(x.abs().max()), "conv3x3 (f16x3) input")
+        _check_f16_range(absmax(x), "conv3x3 (f16x3) input")
         _check_f16_weight_range(wp, "conv3x3 (f16x3)")
     fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
     _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
