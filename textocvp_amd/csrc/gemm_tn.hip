@@ -18,6 +18,8 @@
 //     slice of `c_part` (+ (N) of `bias_part`), written or accumulated in place -- the caller keeps one
 //     partial buffer per weight for the whole backward pass (all rollout steps add into it) and reduces the
 //     splits once at the end, in a fixed order: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -148,41 +150,56 @@ __global__ __launch_bounds__(256, TN_STAGES == 3 ? 3 : 2) void gemm_tn_f32_kerne
 typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tn_bf16x4 __attribute__((ext_vector_type(4)));
 typedef short tn_s16x4 __attribute__((ext_vector_type(4)));
-constexpr int TB_ROWS = 32, TB_RS = 320, TB_PLANE = TB_ROWS * TB_RS, TB_OPER = 2 * TB_PLANE, TB_STAGE = 2 * TB_OPER;
+constexpr int TB_ROWS = 32;
 
+template <int RS>
 __device__ __forceinline__ tn_bf16x8 tn_tr_frag(const unsigned char* addr) {
     typedef __attribute__((address_space(3))) tn_s16x4* lp;
     union { tn_s16x4 s[2]; tn_bf16x8 b; } u;
     u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(addr));
-    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(addr + 4 * TB_RS));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(addr + 4 * RS));
     return u.b;
 }
 
+// MI = 2: 128 (n) x 128 (k) output tile, a wave owns 64 x 64, two LDS stages (80 KB), one barrier per stage.
+// MI = 4: 256 (n) x 128 (k), a wave owns 128 x 64 = 4 x 2 accumulator tiles (the kernel is LDS- and VALU-bound: per
+//         stage and wave 32 transposed reads + 16 plane stores + 32 elements to split for 24 MFMAs at MI = 2; 48 + 24
+//         + 48 for 48 MFMAs at MI = 4); ONE LDS stage (56 KB, two workgroups per CU) filled from registers behind a
+//         second barrier.  Measured slower in the training step (see the launch function): off by default.
+template <int MI>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TB_STAGE];
+    constexpr int GN = 64 * MI;                                   // columns of the G (n) tile
+    constexpr int RSG = GN * 2 + 64, RSX = 320;                   // row pitches: 64 bytes past a multiple of 256
+    constexpr int GPLANE = TB_ROWS * RSG, XPLANE = TB_ROWS * RSX;
+    constexpr int STAGE = 2 * GPLANE + 2 * XPLANE, NSTAGE = MI == 2 ? 2 : 1;
+    constexpr int GPT = GN / 32;                                  // float4 of G per thread and stage (4 or 8)
+    constexpr int GTR = GN / 4, GRS = 256 / GTR;                  // threads per G row, rows per staging pass
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int wy = wave >> 1, wx = wave & 1;
-    const int k0 = blockIdx.x * TN_T, n0 = blockIdx.y * TN_T, z = blockIdx.z;
+    const int k0 = blockIdx.x * TN_T, n0 = blockIdx.y * GN, z = blockIdx.z;
     const int r_lo = min(p.M, z * p.chunk), r_hi = min(p.M, r_lo + p.chunk);
     const int nit = (r_hi - r_lo) / TB_ROWS;
     if (nit == 0 && p.accumulate) return;          // nothing to add (workgroup-uniform)
 
-    // staging: thread t moves rows sr, sr + 8, sr + 16, sr + 24 of the stage, columns sc .. sc + 3 of both operands
-    const int sr = t >> 5, sc = (t & 31) * 4;
+    // staging: G rows gr + GRS * i, columns gc .. gc + 3;  X rows xr + 8 * i, columns xc .. xc + 3
+    const int gr = t / GTR, gc = (t % GTR) * 4;
+    const int xr = t >> 5, xc = (t & 31) * 4;
     const bool want_bias = p.bias != nullptr && blockIdx.x == 0;        // workgroup-uniform
-    f32x4 gq[4], xq[4];
+    f32x4 gq[GPT], xq[4];
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int it) {
-        const size_t row = (size_t)(r_lo + it * TB_ROWS + sr);
+        const size_t row = (size_t)(r_lo + it * TB_ROWS);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gq[i] = *reinterpret_cast<const f32x4*>(p.G + (row + 8 * i) * p.ldg + n0 + sc);
-            xq[i] = *reinterpret_cast<const f32x4*>(p.X + (row + 8 * i) * p.ldx + k0 + sc);
-        }
+        for (int i = 0; i < GPT; ++i)
+            gq[i] = *reinterpret_cast<const f32x4*>(p.G + (row + gr + GRS * i) * p.ldg + n0 + gc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xq[i] = *reinterpret_cast<const f32x4*>(p.X + (row + xr + 8 * i) * p.ldx + k0 + xc);
     };
-    auto split_store = [&](unsigned char* dst, const f32x4 v) {
+    auto split_store = [&](unsigned char* dst, int plane, const f32x4 v) {
         tn_bf16x4 hi, lo;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -190,49 +207,54 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
             lo[u] = (__bf16)(v[u] - (float)hi[u]);
         }
         *reinterpret_cast<tn_bf16x4*>(dst) = hi;
-        *reinterpret_cast<tn_bf16x4*>(dst + TB_PLANE) = lo;
+        *reinterpret_cast<tn_bf16x4*>(dst + plane) = lo;
     };
     auto lstore = [&](int buf) {
-        unsigned char* st = lds + buf * TB_STAGE + sr * TB_RS + sc * 2;
+        unsigned char* st = lds + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            split_store(st + 8 * i * TB_RS, gq[i]);
-            split_store(st + TB_OPER + 8 * i * TB_RS, xq[i]);
+        for (int i = 0; i < GPT; ++i) {
+            split_store(st + (gr + GRS * i) * RSG + gc * 2, GPLANE, gq[i]);
             if (want_bias) bs += gq[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_store(st + 2 * GPLANE + (xr + 8 * i) * RSX + xc * 2, XPLANE, xq[i]);
     };
 
     float* C = p.C + (size_t)z * p.N * p.K;
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                const int n = n0 + wy * 32 * MI + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
                 acc[i][j][r] = p.accumulate ? C[(size_t)n * p.K + k] : 0.f;
             }
 
     // transposed-read address of this lane inside a 16-row k-step: the 16-lane group (lane >> 4) & 1 takes columns
     // 16 .. 31 of the fragment, lane 4q + p of a group supplies row 8h + q, columns 4p .. 4p + 3
     const int i16 = lane & 15, c16 = ((lane >> 4) & 1) * 16;
-    const int rd_off = (8 * h + (i16 >> 2)) * TB_RS + (c16 + 4 * (i16 & 3)) * 2;
+    const int g_off = (8 * h + (i16 >> 2)) * RSG + (c16 + 4 * (i16 & 3)) * 2 + wy * 64 * MI;
+    const int x_off = (8 * h + (i16 >> 2)) * RSX + (c16 + 4 * (i16 & 3)) * 2 + wx * 128;
     auto compute = [&](int buf) {
-        const unsigned char* gs = lds + buf * TB_STAGE + rd_off + wy * 128;
-        const unsigned char* xs = lds + buf * TB_STAGE + TB_OPER + rd_off + wx * 128;
+        const unsigned char* gs = lds + buf * STAGE + g_off;
+        const unsigned char* xs = lds + buf * STAGE + 2 * GPLANE + x_off;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            tn_bf16x8 ah[2], al[2], bh[2], bl[2];
+            tn_bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = tn_tr_frag(gs + kk * 16 * TB_RS + i * 64);
-                al[i] = tn_tr_frag(gs + kk * 16 * TB_RS + i * 64 + TB_PLANE);
-                bh[i] = tn_tr_frag(xs + kk * 16 * TB_RS + i * 64);
-                bl[i] = tn_tr_frag(xs + kk * 16 * TB_RS + i * 64 + TB_PLANE);
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = tn_tr_frag<RSG>(gs + kk * 16 * RSG + i * 64);
+                al[i] = tn_tr_frag<RSG>(gs + kk * 16 * RSG + i * 64 + GPLANE);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = tn_tr_frag<RSX>(xs + kk * 16 * RSX + j * 64);
+                bl[j] = tn_tr_frag<RSX>(xs + kk * 16 * RSX + j * 64 + XPLANE);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
@@ -250,28 +272,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
     for (int it = 0; it < nit; ++it) {
         const bool more = it + 1 < nit;               // workgroup-uniform
         if (more) gload(it + 1);
-        compute(it & 1);
-        if (more) lstore((it + 1) & 1);
-        __syncthreads();
+        if (NSTAGE == 2) {
+            compute(it & 1);
+            if (more) lstore((it + 1) & 1);
+            __syncthreads();
+        } else {
+            compute(0);
+            __syncthreads();                          // every wave has read the stage
+            if (more) lstore(0);
+            __syncthreads();
+        }
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wy * 64 + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
+                const int n = n0 + wy * 32 * MI + i * 32 + acc_row(r, h), k = k0 + wx * 64 + j * 32 + l31;
                 C[(size_t)n * p.K + k] = acc[i][j][r];
             }
-    if (want_bias) {                                  // 8 threads (sr = 0 .. 7) share the columns sc .. sc + 3
+    if (want_bias) {                                  // GRS threads (gr = 0 .. GRS - 1) share the columns gc .. gc + 3
         float* red = reinterpret_cast<float*>(lds);
-        *reinterpret_cast<f32x4*>(red + sr * 128 + sc) = bs;
+        *reinterpret_cast<f32x4*>(red + gr * GN + gc) = bs;
         __syncthreads();
-        if (t < 128) {
+        if (t < GN) {
             float v = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v += red[q * 128 + t];
+            for (int q = 0; q < GRS; ++q) v += red[q * GN + t];
             float* b = p.bias + (size_t)z * p.N + n0 + t;
             *b = p.accumulate ? *b + v : v;
         }
@@ -311,7 +340,19 @@ extern "C" int tocvp_gemm_tn_bf16x3_f32(const float* G, int ldg, const float* X,
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TB_ROWS - 1) / TB_ROWS * TB_ROWS;
     TnArgs a{G, X, c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
-    const dim3 grid(K / TN_T, N / TN_T, splits);
-    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // 256-row tiles (MI = 4) when they still give this many workgroups.  OFF by default: at the configs[1] shapes the
+    // training step measures 511.8 ms without them, 520.3 ms with them from 256 workgroups up and 529.5 ms from 128 up --
+    // the single LDS stage's second barrier costs more than the shared fragments save.  TOCVP_TN_WIDE_MIN_WGS=256 tries it.
+    static const long wide_min = []() {
+        const char* e = getenv("TOCVP_TN_WIDE_MIN_WGS");
+        return e ? atol(e) : (1L << 40);
+    }();
+    if (N % 256 == 0 && (long)(K / TN_T) * (N / 256) * splits >= wide_min) {
+        const dim3 grid(K / TN_T, N / 256, splits);
+        hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    } else {
+        const dim3 grid(K / TN_T, N / TN_T, splits);
+        hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    }
     return tocvp_launch_status();
 }
