@@ -223,6 +223,16 @@ def test_graph_replay_of_the_evaluation_is_bit_identical():
     assert len(graphed._graphs) == 2
     with pytest.raises(ValueError):
         graphed(videos.cpu(), **others)
+    # without init_noise the initialiser's Gaussian is drawn per call on the CPU generator, as the eager forward does
+    # (a replay must not freeze the draw of the capturing call)
+    plain = {k: v for k, v in others.items() if k != "init_noise"}
+    torch.manual_seed(123)
+    e1 = forward_eval(savi, pred, videos, 2, 4, overlap_decode=False, **plain)["pred_imgs"].clone()
+    e2 = forward_eval(savi, pred, videos, 2, 4, overlap_decode=False, **plain)["pred_imgs"].clone()
+    torch.manual_seed(123)
+    g1 = graphed(videos, **plain)["pred_imgs"].clone()
+    g2 = graphed(videos, **plain)["pred_imgs"].clone()
+    assert torch.equal(g1, e1) and torch.equal(g2, e2) and not torch.equal(e1, e2)
     # new weights: the graphs (raw pointers to the old operand planes) are dropped and captured again
     with torch.no_grad():
         pred.predictor.predictor[0].mlp[0].weight.mul_(1.25)

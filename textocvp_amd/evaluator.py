@@ -151,10 +151,24 @@ class GraphedEval:
             out["epilogue"] = self.epilogue(out)
         return out
 
+    def _with_init_noise(self, videos, others):
+        """ The random slot initialiser draws one Gaussian per forward on the CPU generator (initializers.py:93 in the
+        reference); a replay would freeze the capture's draw.  Draw it here, per call, exactly as the eager forward
+        would, and hand it to the graph as an input. """
+        if "init_noise" in others:
+            return others
+        model = getattr(self.decomp_model, "module", self.decomp_model)
+        init = getattr(model, "initializer", None)
+        if init is None or not hasattr(init, "slots_sigma"):
+            return others
+        noise = torch.randn((videos.shape[0], init.num_slots, init.slot_dim))
+        return dict(others, init_noise=noise.to(videos.device))
+
     @torch.no_grad()
     def __call__(self, videos, **others):
         if not videos.is_cuda:
             raise ValueError("GraphedEval replays a HIP graph: the inputs must live on the GPU")
+        others = self._with_init_noise(videos, others)
         weights = self._weights_signature()
         if weights != self._weights:
             self._graphs, self._weights = {}, weights
