@@ -562,14 +562,14 @@ def test_conv5x5_dec_f16x3_is_fp32_class(n):
         assert torch.equal(y.cpu(), want), (pm_in, pm_out)
 
 
-@pytest.mark.parametrize("n", [3, 21])
-def test_conv5x5_dec_f16x3_operand_planes_between_layers(n):
+@pytest.mark.parametrize("n,HW", [(3, 64), (21, 64), (2, 128)])
+def test_conv5x5_dec_f16x3_operand_planes_between_layers(n, HW):
     """ two layers chained through fp16 operand planes (producer epilogue writes [Xh | Xl] per pixel and pass, the
     consumer stages them by LDS-DMA) == the same layers chained through fp32 pass-major buffers, bit for bit, and a
     three-layer chain planes -> planes -> NHWC as the decoder runs it; image borders, saturating values and exact
-    zeros included """
+    zeros included; 128 x 128 is the largest image whose DMA source offsets fit their 16-bit form """
     k = _k()
-    x = rnd("px", (n, 64, 64, 64))
+    x = rnd(f"px{HW}", (n, HW, HW, 64))
     x[0, :4, :4] = 0.0
     x[0, 5, 5, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 1e-3, 40.0, -90.0, 200.0, 0.25])
     x[1] = x[1] * 1e-3
@@ -590,8 +590,8 @@ def test_conv5x5_dec_f16x3_operand_planes_between_layers(n):
     assert torch.equal(y3_p, y3_f)
     assert float(y1_f.max()) > 255.0                     # the saturating case is really in the data
     # the planes buffer itself: hi + lo of 2^8 y, saturated at the fp16 range, per pixel and pass
-    pl = y1_p.view(torch.float16).view(n, 4, 64, 64, 2, 16).float()
-    want = (y1_f.view(n, 4, 64, 64, 16) * 256.0).clamp(-65504.0, 65504.0)
+    pl = y1_p.view(torch.float16).view(n, 4, HW, HW, 2, 16).float()
+    want = (y1_f.view(n, 4, HW, HW, 16) * 256.0).clamp(-65504.0, 65504.0)
     assert (pl.sum(4) - want).abs().max().item() <= 2.0 ** -10 * 256.0 * 255.0 * 2.0 ** -11
     # against fp64 through all three layers (inputs of layer 2 / 3 saturate where layer 1 exceeded the range, so the
     # reference clamps the same way)

@@ -761,6 +761,8 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
     // operand planes (written by / read from a neighbouring layer of this kernel; not with the persistent form)
     TOCVP_CHECK_ARG(layout >= 0 && layout <= 15 && !(in_mode == 1 && (layout & 1)));
     TOCVP_CHECK_ARG(!(layout & 8) || ((layout & 3) != 0 && !(layout & 4)));
+    // planes input: the DMA source offsets are kept as 16-bit counts of 16-byte pieces inside one pass plane
+    TOCVP_CHECK_ARG((layout & 9) != 9 || (long)H * W <= 16384);
     TOCVP_CHECK_ARG(x && wf && bias && y);
     TOCVP_CHECK_ARG(in_mode == 0 || (in_mode == 1 && aux != nullptr));
     TOCVP_CHECK_ARG(Cin == C && Cout == C);

@@ -156,7 +156,8 @@ class ConvDecoder(nn.Module):
                     if self.conv_precision == "f16x3":
                         x = K.conv5x5_dec_f16x3(x, self._split16(i), conv.bias, relu=True, out=out,
                                                 collapsed=(cpos, S) if i == 1 else None,
-                                                pm_in=pm_prev, pm_out=pm_out, planes=self.conv_planes)
+                                                pm_in=pm_prev, pm_out=pm_out,
+                                                planes=self.conv_planes and H * W <= 16384)
                     else:
                         x = K.conv5x5_f16f8(x, self._hybrid(i), conv.bias, relu=True, out=out,
                                             collapsed=(cpos, S) if i == 1 else None,
