@@ -236,6 +236,18 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_small_kernel(XArgs p) 
     const int b = blockIdx.y, r0 = blockIdx.x * 32;
     const float* xb = p.x + (size_t)b * p.Tq * E;
 
+    // The caption operands do not depend on anything computed here: the first eight k-steps of this wave's G fragments
+    // take off before the LayerNorm and the ring stays eight steps ahead of the MFMAs (one step ahead, each of the 32
+    // dependent k-steps waited a full L2 round trip: 19 of the kernel's 28 us at one sequence)
+    constexpr int GRING = 8;
+    const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + wave) * (E / 16) * 2) * 64 + lane;
+    f16x8 gh[GRING], gl[GRING];
+#pragma unroll
+    for (int d = 0; d < GRING; ++d) {
+        gh[d] = gf[(size_t)d * 128];
+        gl[d] = gf[(size_t)d * 128 + 64];
+    }
+
     // ---- phase 0: LayerNorm of rows 8 wave .. 8 wave + 7 (rows past Tq repeat the last row; never stored)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -280,23 +292,35 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_small_kernel(XArgs p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     {
-        const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + wave) * (E / 16) * 2) * 64 + lane;
         const unsigned char* xl = lds + l31 * XROW1 + hh * 16;
-        f16x8 gh = gf[0], gl = gf[64];
-#pragma unroll 4
+#pragma unroll
         for (int ks = 0; ks < E / 16; ++ks) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + ks * 32);
             const f16x8 al = *reinterpret_cast<const f16x8*>(xl + E * 2 + ks * 32);
-            const f16x8 wh = gh, wl = gl;
-            if (ks + 1 < E / 16) {
-                gh = gf[(size_t)(ks + 1) * 128];
-                gl = gf[(size_t)(ks + 1) * 128 + 64];
+            const f16x8 wh = gh[ks % GRING], wl = gl[ks % GRING];
+            if (ks + GRING < E / 16) {
+                gh[ks % GRING] = gf[(size_t)(ks + GRING) * 128];
+                gl[ks % GRING] = gf[(size_t)(ks + GRING) * 128 + 64];
             }
             sacc = mfma16(wh, al, sacc);
             sacc = mfma16(wl, ah, sacc);
             sacc = mfma16(wh, ah, sacc);
         }
     }
+    // the output-projection fragments of the first k-steps fly under the softmax and the two barriers behind it
+    constexpr int HRING = 3;
+    f16x8 hw[HRING][4][2];
+    auto load_h = [&](int slot, int ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8* hf = reinterpret_cast<const f16x8*>(p.Hf) +
+                              (((size_t)(b * (E / 32) + wave * 4 + j) * (NP / 16) + ks) * 2) * 64 + lane;
+            hw[slot][j][0] = hf[0];
+            hw[slot][j][1] = hf[64];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < HRING; ++d) load_h(d, d);
     // softmax over the caption slots of each head: register r of lane half hh = slot t = 4 hh + (r & 3) + 8 ((r >> 2) & 1)
     // of head 2 wave + (r >> 3); the other half of the slots sits in lane ^ 32
     float pr[16];
@@ -355,14 +379,18 @@ __global__ __launch_bounds__(256, 2) void xattn_collapsed_small_kernel(XArgs p) 
         for (int ks = 0; ks < NP / 16; ++ks) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(pl + ks * 32);
             const f16x8 al = *reinterpret_cast<const f16x8*>(pl + NP * 2 + ks * 32);
+            f16x8 wh[4], wl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f16x8* hf = reinterpret_cast<const f16x8*>(p.Hf) +
-                                  (((size_t)(b * (E / 32) + wave * 4 + j) * (NP / 16) + ks) * 2) * 64 + lane;
-                const f16x8 wh = hf[0], wl = hf[64];
-                yacc[j] = mfma16(wh, al, yacc[j]);
-                yacc[j] = mfma16(wl, ah, yacc[j]);
-                yacc[j] = mfma16(wh, ah, yacc[j]);
+                wh[j] = hw[ks % HRING][j][0];
+                wl[j] = hw[ks % HRING][j][1];
+            }
+            if (ks + HRING < NP / 16) load_h(ks % HRING, ks + HRING);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                yacc[j] = mfma16(wh[j], al, yacc[j]);
+                yacc[j] = mfma16(wl[j], ah, yacc[j]);
+                yacc[j] = mfma16(wh[j], ah, yacc[j]);
             }
         }
     }
