@@ -432,12 +432,20 @@ def main():
             n = max(2, args.steps)
             inp_b = make_inputs(b)
             el_eager, _, _ = timed(inp_b, 1, n)
-            el, _, _ = timed(inp_b, 2, n, step=step_graphed)       # warm-up 1 captures, warm-up 2 replays
+            try:
+                if world > 1:          # ranks must never diverge inside a collective: replay is a 1-GPU figure
+                    raise RuntimeError("graph replay is timed on one GPU only")
+                el, _, _ = timed(inp_b, 2, n, step=step_graphed)   # warm-up 1 captures, warm-up 2 replays
+            except Exception as err:                              # a failed capture must not take the line with it
+                log(f"graph replay at batch {b} failed ({type(err).__name__}: {err}); eager figure only")
+                kernels.TIMER = None
+                torch.cuda.synchronize()
+                el = float("inf")
             best = min(el, el_eager)
             extra[f"batch_{b}"] = {"value": round(world * b * NUM_PREDS * n / best, 2), "unit": "predicted frames/s",
                                    "batch_per_gpu": b, "ms_per_step": round(1e3 * best / n, 2),
                                    "mode": "graph" if el <= el_eager else "eager",
-                                   "ms_per_step_graph": round(1e3 * el / n, 2),
+                                   "ms_per_step_graph": round(1e3 * el / n, 2) if el != float("inf") else None,
                                    "ms_per_step_eager": round(1e3 * el_eager / n, 2),
                                    "note": notes[b] + "; graph: the step replayed from a captured HIP graph "
                                            "(evaluator.GraphedEval, serial decode); eager: launched from Python, "

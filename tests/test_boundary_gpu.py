@@ -274,5 +274,19 @@ def test_rccl_branch_on_a_world_of_one_rank():
         torch.cuda.synchronize()
         for g0, v in zip(before, step._grads()):
             assert torch.equal(g0, v.grad)                      # average over one rank = identity, through RCCL
+        # graph capture with the RCCL process group (and its watchdog thread) alive, as in bench.py's small-batch
+        # legs: the capture must not be invalidated by what other threads do, and collectives work after it
+        exp2, savi2, pred2 = _fresh(7, 3)
+        savi2, pred2 = savi2.to(DEV), pred2.to(DEV)
+        vid = synth.synth_videos(2, 4, seed=3).to(DEV)
+        tok, ln = synth.synth_captions(2, max_len=12, seed=3)
+        kw = {"caption_tokens": tok.to(DEV), "caption_lengths": ln.to(DEV),
+              "init_noise": synth.synth_noise(2, 7, 128, seed=4).to(DEV)}
+        eager = forward_eval(savi2, pred2, vid, 1, 3, overlap_decode=False, **kw)["pred_imgs"].clone()
+        graphed = GraphedEval(savi2, pred2, 1, 3)
+        for _ in range(3):
+            assert torch.equal(graphed(vid, **kw)["pred_imgs"], eager)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()

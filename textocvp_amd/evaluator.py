@@ -184,7 +184,9 @@ class GraphedEval:
                 if torch.is_tensor(v):
                     static_o[k].copy_(v)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture mode: calls other threads make meanwhile (the RCCL watchdog polling its events
+            # when a process group is alive) must not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._run(static_v, static_o)
             entry = (static_v, static_o, graph, out)
             self._graphs[key] = entry
