@@ -335,11 +335,12 @@ class PredictorTrainStep:
             gen = self.model.generator
             if gen is not None and hasattr(g1, "register_generator_state"):
                 g1.register_generator_state(gen)
-            with torch.cuda.graph(g1):
+            # thread-local capture mode: the RCCL watchdog of a live process group must not invalidate the capture
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 self._static_out = self._forward_backward(*self._static)
             self._set_hyper()
             self.iteration -= 1                                               # capture does not count as a step
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 self._static_clip = self._optimizer_kernels()
             self._graphs = (g1, g2)
             return warm                        # capturing records kernels, it does not run them
