@@ -313,6 +313,24 @@ int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, c
                                 const float* bias, float* y, int nimg, int H, int W, int Cin, int Cout,
                                 int relu, int layout, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Decoder tail folded into the last hidden layer.  The tail Conv2d(64 -> 4, k = 3) (decoders.py:112-117) is linear,
+ * so the last 5 x 5 layer's epilogue multiplies every pixel's 64 outputs (bias + ReLU applied, still on the chip,
+ * no halo) with the 36 x 64 tap matrix (rows 4 t + o, t = 3 ky + kx) in the same split-fp16 arithmetic and writes
+ * `products` (nimg, 36, H, W) fp32 instead of the 64-channel activation; tocvp_dec_tail_sum_f32 then forms
+ *     rgba[o](p) = bias[o] + sum_t products[4 t + o](p + off_t)            (zero outside the image)
+ * the softmax of alpha over the K slot images of a frame and the composited frame -- the outputs of
+ * tocvp_dec_tail_f32 (SAVi.py:251-255).  tail_taps: image written by tocvp_pack_tail_taps_f16x3 from the tail
+ * weight (4, 64, 3, 3), tocvp_tail_taps_f16x3_bytes() bytes.  layout: bit 0 pass-major input, bit 3 operand planes in
+ * it, as for tocvp_conv5x5_dec_f16x3_f32.  Valid for |activation| < 255, |tail weight| < 63 (saturating beyond).
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_tail_taps_f16x3_bytes(void);
+int tocvp_pack_tail_taps_f16x3(const float* w, void* out, void* stream);
+int tocvp_conv5x5_dec_f16x3_tail_f32(const float* x, const void* wf, const float* bias, const void* tail_taps,
+                                     float* products, int nimg, int H, int W, int relu, int layout, void* stream);
+int tocvp_dec_tail_sum_f32(const float* products, const float* bias, float* recons_imgs, float* recons, float* masks,
+                           int F, int K, int H, int W, void* stream);
+
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of
  *   w[co,ci,dy,dx];  w: (Cout,Cin,5,5), out: (25,Cout,Cin). */

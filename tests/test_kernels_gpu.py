@@ -237,6 +237,48 @@ def test_dec_tail(Fr, K):
     close(g_imgs, imgs)
 
 
+@pytest.mark.parametrize("Fr,K", [(2, 7), (1, 30)])
+def test_decoder_tail_folded_into_the_last_layer(Fr, K):
+    """ last 5 x 5 layer + tail: the tap products of the folded epilogue (36 per pixel, split-fp16 arithmetic) summed by
+    tocvp_dec_tail_sum_f32 against (i) fp64 conv -> conv3x3 -> softmax -> compositing and (ii) the unfused kernels
+    (f16x3 layer, exact-fp32 tail), for NHWC and for operand-plane input; image borders carry the zero padding of both
+    convolutions """
+    k = _k()
+    n = Fr * K
+    x = rnd("fx", (n, 64, 64, 64))
+    x[0, :3, :5] = 0.0
+    w3 = rnd("fw3", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b3 = rnd("fb3", (64,), "uniform", 0.1)
+    wt = rnd("fwt", (4, 64, 3, 3), "uniform", 0.1)
+    bt = rnd("fbt", (4,), "uniform", 0.3)
+    y3 = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w3.double(), b3.double(), padding=2))
+    y = F.conv2d(y3, wt.double(), bt.double(), padding=1).reshape(Fr, K, 4, 64, 64)
+    ref_rec, ref_masks = y[:, :, :3], torch.softmax(y[:, :, 3:], dim=1)
+    ref_imgs = (ref_rec * ref_masks).sum(1)
+    xd, wf, bd = x.to(DEV), k.split_conv_weights_dec_f16x3(w3.to(DEV)), b3.to(DEV)
+    taps = k.pack_tail_taps_f16x3(wt.to(DEV))
+    # unfused
+    y3_d = k.conv5x5_dec_f16x3(xd, wf, bd, relu=True)
+    u_imgs, u_rec, u_masks = k.dec_tail(y3_d, wt.to(DEV), bt.to(DEV), Fr, K)
+    # folded, NHWC input
+    P = k.conv5x5_dec_f16x3_tail(xd, wf, bd, taps, relu=True)
+    imgs, rec, masks = k.dec_tail_sum(P, bt.to(DEV), Fr, K)
+    for got, un, ref, name in ((rec, u_rec, ref_rec, "recons"), (masks, u_masks, ref_masks, "masks"),
+                               (imgs, u_imgs, ref_imgs, "imgs")):
+        e_f = (got.cpu().double() - ref.reshape(got.shape)).abs().max().item()
+        e_u = (un.cpu().double() - ref.reshape(un.shape)).abs().max().item()
+        print(f"folded tail {name}: err {e_f:.2e} (unfused {e_u:.2e})")
+        assert e_f < max(3.0 * e_u, 3e-6 * max(1.0, ref.abs().max().item()))
+    # folded, operand-plane input written by a previous layer == the same through fp32 pass-major
+    w2 = rnd("fw2", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    wf2 = k.split_conv_weights_dec_f16x3(w2.to(DEV))
+    mid_p = k.conv5x5_dec_f16x3(xd, wf2, bd, relu=True, pm_out=True, planes=True)
+    mid_f = k.conv5x5_dec_f16x3(xd, wf2, bd, relu=True, pm_out=True, planes=False)
+    P_p = k.conv5x5_dec_f16x3_tail(mid_p, wf, bd, taps, relu=True, pm_in=True, planes=True)
+    P_f = k.conv5x5_dec_f16x3_tail(mid_f, wf, bd, taps, relu=True, pm_in=True, planes=False)
+    assert torch.equal(P_p, P_f)
+
+
 def test_text_embed():
     k = _k()
     tokens, _ = synth.synth_captions(3, max_len=20, lengths=[5, 12, 20], seed=3)

@@ -355,10 +355,12 @@ def test_e2e_against_oracle_fresh_inputs(k7):
     assert max_abs(out["slot_history"].cpu(), hist) < 1e-4
     assert max_abs(out["pred_slots"].cpu(), preds) < 1e-4
     assert max_abs(out["pred_imgs"].cpu(), imgs) < 1e-4
-    # one pixel whose two largest masks differ by 2.1e-7 in the oracle (a few fp32 ulps) goes the other way since the
-    # skinny GEMMs of small batches add their K slices in a different order (split-K, gemm_bf16.hip): a named tie
+    # at most one pixel whose two largest masks are within fp32 rounding of each other in the oracle may go the other
+    # way: 2.1e-7 when the skinny GEMMs began to add their K slices in another order (split-K), none with the decoder
+    # conv's dx-major taps, 6.3e-7 (five ulps of a mask of ~0.1) since the tail's taps are multiplied in the last
+    # layer's epilogue in split-fp16 arithmetic.  The reference-generated fixtures above all stay at zero.
     assert_same_slot_assignment(out["masks"], masks.argmax(dim=1), "e2e fresh inputs vs oracle (K=7, B=3)",
-                                ties=1, tie_margin=5e-7)
+                                ties=1, tie_margin=1e-6)
 
 
 @torch.no_grad()

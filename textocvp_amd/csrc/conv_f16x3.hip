@@ -81,6 +81,8 @@ struct Args {
     int pm_in, pm_out;      // pass-major activation layout (n, 4, H, W, 16) instead of NHWC (n, H, W, 64);
                             // pm_out == 2 (and the PLANES_IN kernel): the 64 bytes of a pixel and pass hold the
                             // operand planes [16 f16 Xh | 16 f16 Xl] of 2^8 x instead of 16 floats
+    const unsigned char* tail_wf;   // != NULL: the decoder tail is folded into this layer's epilogue (below): y is then
+                                    // the (n, 36, H, W) fp32 array of per-pixel tap products, not the 64-channel output
 };
 
 __device__ __forceinline__ int border_class(int p, int n) {
@@ -99,7 +101,7 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
 // lane): the image is 4080 chunks of 16 bytes (816 pixels x [Xh 0-7 | Xh 8-15 | Xl 0-7 | Xl 8-15 | pad]), thread t
 // moves chunks t, t + 256, ... with source offsets computed once per tile -- no staging registers, no conversion
 // instructions, no ds_write; pixels outside the image are loaded from a clamped address and zeroed afterwards.
-template <int MODE, bool PLANES_IN = false>
+template <int MODE, bool PLANES_IN = false, bool TAILP = false>
 __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
     constexpr int NT = 256;
     constexpr int SS = C + 4;                                       // padded floats per staged pixel
@@ -417,6 +419,100 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
     // contiguous output (4 pixels x 256 B NHWC, or 16 pixels x 64 B of one pass-major plane).
     float* stage = reinterpret_cast<float*>(lds) + wave * (64 * SS);
     constexpr float UNSCALE = 1.f / (SA * SW);
+    if constexpr (TAILP) {
+        // ---- decoder tail folded in (the last hidden layer).  The tail's 3 x 3 x 64 -> 4 convolution is linear: each
+        // pixel's 64 outputs are multiplied HERE with the 36 x 64 tap matrix (36 = 9 taps x 4 outputs) and only the 36
+        // products P[tap][out](pixel) leave the chip; the tail kernel then adds nine shifted planes.  Per 32-pixel
+        // block of the wave: the outputs (bias + ReLU applied) go to a wave-private LDS image as fp16 planes
+        // [channel][pixel] -- a lane holds one channel of four consecutive pixels per register quad: 8-byte stores --
+        // and come back as the A operand through the hardware transpose (the product sums over the channel, the
+        // LANE index of the accumulator); the tap matrix arrives in fragment order from L2; 24 MFMAs per block.
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lp4;
+        constexpr int TIMG = 64 * 64;                                 // one plane: 64 channel rows x 32 pixels x 2 B
+        constexpr int TPS = 36;                                       // floats per staged product row (32 pixels + pad)
+        unsigned char* timg = lds + wave * (2 * TIMG + 36 * TPS * 4);
+        float* pst = reinterpret_cast<float*>(timg + 2 * TIMG);
+        const int i16 = lane & 15, c16 = ((lane >> 4) & 1) * 16;
+        const unsigned char* trd = timg + (8 * h + (i16 >> 2)) * 64 + (c16 + 4 * (i16 & 3)) * 2;
+        const f16x8* twf = reinterpret_cast<const f16x8*>(p.tail_wf) + lane;       // [nb 2][ks 4][plane 2][lane]
+        f16x8 tb[2][4][2];                                            // the whole tap matrix of this lane: loaded once
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) tb[nb][ks][pl] = twf[((nb * 4 + ks) * 2 + pl) * 64];
+        float* pout = p.y + (size_t)img * 36 * p.H * p.W;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {                                 // m = 2 * (row of the pair) + 32-pixel half
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float bv = p.bias[n * 32 + l31];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                         // registers 4g .. 4g + 3 = pixels 8g + 4h .. + 3
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[m][n][4 * g + e] * UNSCALE + bv;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        const float X = clampf(v * SA, F16MAX);
+                        hi[e] = (_Float16)X;
+                        lo[e] = (_Float16)(X - (float)hi[e]);
+                    }
+                    unsigned char* d = timg + (n * 32 + l31) * 64 + (8 * g + 4 * h) * 2;
+                    *reinterpret_cast<f16x4*>(d) = hi;
+                    *reinterpret_cast<f16x4*>(d + TIMG) = lo;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x16 pacc[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pacc[nb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { s16x4 s[2]; f16x8 f; } ah, al;
+                ah.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(trd + ks * 16 * 64));
+                ah.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(trd + ks * 16 * 64 + 4 * 64));
+                al.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(trd + TIMG + ks * 16 * 64));
+                al.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(trd + TIMG + ks * 16 * 64 + 4 * 64));
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const f16x8 bh = tb[nb][ks][0], bl = tb[nb][ks][1];
+                    pacc[nb] = mfma16(al.f, bh, pacc[nb]);
+                    pacc[nb] = mfma16(ah.f, bl, pacc[nb]);
+                    pacc[nb] = mfma16(ah.f, bh, pacc[nb]);
+                }
+            }
+            // products: lane = column (tap, out) = 32 nb + l31 (36 used), register quad g = pixels 8g + 4h .. + 3
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int to = nb * 32 + l31;
+                if (to < 36) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(pst + to * TPS + 8 * g + 4 * h) =
+                            f32x4{pacc[nb][4 * g] * UNSCALE, pacc[nb][4 * g + 1] * UNSCALE,
+                                  pacc[nb][4 * g + 2] * UNSCALE, pacc[nb][4 * g + 3] * UNSCALE};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int oy = ty0 + 2 * wave + (m >> 1), ox = tx0 + (m & 1) * 32;
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {                          // 36 rows x 8 float4 = 288 pieces
+                const int idx = lane + 64 * it;
+                if (idx < 36 * 8) {
+                    const int to = idx >> 3, c4 = (idx & 7) * 4;
+                    *reinterpret_cast<f32x4*>(pout + ((size_t)to * p.H + oy) * p.W + ox + c4) =
+                        *reinterpret_cast<const f32x4*>(pst + to * TPS + c4);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
 #pragma unroll
@@ -743,6 +839,83 @@ __global__ __launch_bounds__(256) void split_conv_weights_dec_f16x3_kernel(const
     wf[((tapbase + 1 * 2 + nb) * 64 + hh * 32 + c) * 8 + j] = lo;
 }
 
+
+// Tap matrix of the folded decoder tail: Conv2d(64 -> 4, k = 3) weights w (4, 64, 3, 3) as the B operand of the epilogue
+// product, rows (tap, out) = 4 t + o (36 of 64 used), fp16 planes of 2^10 w in fragment order [nb 2][ks 4][plane 2][lane]:
+// lane (column c = l & 31 -> row 32 nb + c, h = l >> 5) holds channels 16 ks + 8 h .. + 7.
+__global__ __launch_bounds__(256) void pack_tail_taps_kernel(const float* __restrict__ w, _Float16* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                   // one fp16 element of one plane pair
+    if (i >= 2 * 4 * 64 * 8) return;
+    const int e = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 3, nb = i >> 11;
+    const int to = nb * 32 + (lane & 31), ch = ks * 16 + 8 * (lane >> 5) + e;
+    float v = 0.f;
+    if (to < 36) v = w[((size_t)(to & 3) * 64 + ch) * 9 + (to >> 2)];
+    const float X = clampf(v * SW, F16MAX);
+    const _Float16 hi = (_Float16)X, lo = (_Float16)(X - (float)hi);
+    _Float16* base = out + (size_t)((nb * 4 + ks) * 2) * 512 + lane * 8 + e;
+    base[0] = hi;
+    base[512] = lo;
+}
+
+// Decoder tail over the tap products P (n = F K slot images, 36, H, W): rgba(p) = bias + sum_t P[4 t + o](p + off_t)
+// (zero outside the image), softmax of alpha over the K slots, compositing -- the three outputs of dec_tail_kernel.
+// One thread per pixel, 4 rows x 64 pixels per workgroup; every P value is read once, coalesced along x.
+__global__ __launch_bounds__(256) void dec_tail_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                           float* __restrict__ recons_imgs, float* __restrict__ recons,
+                                                           float* __restrict__ masks, int K, int H, int W) {
+    const int f = blockIdx.y;
+    const int pix_lin = blockIdx.x * 256 + threadIdx.x;
+    const size_t HW = (size_t)H * W;
+    if (pix_lin >= H * W) return;
+    const int y = pix_lin / W, x = pix_lin % W;
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        ok[t] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[t] = ok[t] ? yy * W + xx : pix_lin;
+    }
+    float* mp = masks + (size_t)f * K * HW + pix_lin;
+    for (int k = 0; k < K; ++k) {
+        const float* Pk = P + ((size_t)f * K + k) * 36 * HW;
+        float v[4] = {b0, b1, b2, b3};
+        float q[36];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) q[4 * t + o] = Pk[(size_t)(4 * t + o) * HW + off[t]];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] += ok[t] ? q[4 * t + o] : 0.f;
+        float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix_lin;
+        ro[0] = v[0];
+        ro[HW] = v[1];
+        ro[2 * HW] = v[2];
+        mp[(size_t)k * HW] = v[3];                                   // raw alpha, normalised in place below
+    }
+    float m = -1.0e30f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, mp[(size_t)k * HW]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += expf(mp[(size_t)k * HW] - m);
+    const float inv = 1.0f / sum;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float mk = expf(mp[(size_t)k * HW] - m) * inv;
+        mp[(size_t)k * HW] = mk;
+        const float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix_lin;
+        c0 += ro[0] * mk;
+        c1 += ro[HW] * mk;
+        c2 += ro[2 * HW] * mk;
+    }
+    float* co = recons_imgs + (size_t)f * 3 * HW + pix_lin;
+    co[0] = c0;
+    co[HW] = c1;
+    co[2 * HW] = c2;
+}
+
 }  // namespace
 
 extern "C" size_t tocvp_conv_weights_dec_f16x3_bytes(void) { return (size_t)NPASS * NTAP * TAP_BYTES; }
@@ -806,5 +979,54 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
         hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<0, false>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<1, false>), grid, dim3(256), 0, s, a);
+    return tocvp_launch_status();
+}
+
+/* ---- decoder tail folded into the last hidden layer -------------------------------------------------------------- */
+extern "C" size_t tocvp_tail_taps_f16x3_bytes(void) { return (size_t)2 * 4 * 2 * 64 * 16; }
+
+extern "C" int tocvp_pack_tail_taps_f16x3(const float* w, void* out, void* stream) {
+    TOCVP_CHECK_ARG(w && out);
+    if (!tocvp_aligned16(out)) return TOCVP_EALIGN;
+    hipLaunchKernelGGL(pack_tail_taps_kernel, dim3((2 * 4 * 64 * 8 + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, static_cast<_Float16*>(out));
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_conv5x5_dec_f16x3_tail_f32(const float* x, const void* wf, const float* bias, const void* tail_taps,
+                                                float* products, int nimg, int H, int W, int relu, int layout,
+                                                void* stream) {
+    // layout: bit 0 pass-major input, bit 3 operand planes in it (as tocvp_conv5x5_dec_f16x3_f32); the output is always
+    // the (nimg, 36, H, W) array of tap products
+    TOCVP_CHECK_ARG(x && wf && bias && tail_taps && products);
+    TOCVP_CHECK_ARG((layout & ~9) == 0 && ((layout & 8) == 0 || (layout & 1)));
+    TOCVP_CHECK_ARG(nimg >= 0 && H > 0 && W > 0 && (H % TH) == 0 && (W % TW) == 0);
+    TOCVP_CHECK_ARG((size_t)nimg * (H / TH) * (W / TW) < 0x7fffffffu && (size_t)H * W * C * 4 < 0x7fffffffu);
+    TOCVP_CHECK_ARG((layout & 9) != 9 || (long)H * W <= 16384);
+    if (!tocvp_aligned16(x) || !tocvp_aligned16(wf) || !tocvp_aligned16(products) || !tocvp_aligned16(tail_taps))
+        return TOCVP_EALIGN;
+    if (nimg == 0) return TOCVP_OK;
+    Args a{x, nullptr, static_cast<const unsigned char*>(wf), bias, products, nimg, H, W, relu, layout & 1, 0,
+           static_cast<const unsigned char*>(tail_taps)};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#if TOCVP_CONV_XCD
+    const dim3 grid((unsigned)((size_t)((nimg + 7) / 8) * 8 * (H / TH) * (W / TW)));
+#else
+    const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
+#endif
+    if ((layout & 9) == 9)
+        hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<0, true, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv5x5_dec_f16x3_kernel<0, false, true>), grid, dim3(256), 0, s, a);
+    return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_tail_sum_f32(const float* products, const float* bias, float* recons_imgs, float* recons,
+                                      float* masks, int F, int K, int H, int W, void* stream) {
+    TOCVP_CHECK_ARG(products && bias && recons_imgs && recons && masks);
+    TOCVP_CHECK_ARG(F >= 0 && F <= 65535 && K > 0 && H > 0 && W > 0 && (long)H * W < (1L << 30));
+    if (F == 0) return TOCVP_OK;
+    hipLaunchKernelGGL(dec_tail_sum_kernel, dim3((unsigned)((H * W + 255) / 256), F), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), products, bias, recons_imgs, recons, masks, K, H, W);
     return tocvp_launch_status();
 }

@@ -56,6 +56,14 @@ _SIGNATURES = {
     "tocvp_gemm_f16planes_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_tail_taps_f16x3_bytes": (ctypes.c_size_t, []),
+    "tocvp_pack_tail_taps_f16x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_conv5x5_dec_f16x3_tail_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_dec_tail_sum_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_absmax_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_gemm_wfrag_ws_bytes": (ctypes.c_size_t, []),
     "tocvp_gemm_f16wfrag_ws_f32": (ctypes.c_int, [
@@ -890,6 +898,58 @@ def dec_tail(x, w, bias, F, K, out=None):
     _check(lib().tocvp_dec_tail_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs),
                                     _ptr(recons), _ptr(masks), F, K, H, W, Cin, _ptr(ws),
                                     ws.numel() * 4, _stream()), "tocvp_dec_tail_f32")
+    return imgs, recons, masks
+
+
+def pack_tail_taps_f16x3(w):
+    """ tail Conv2d(64 -> 4, k = 3) weight (4, 64, 3, 3) -> tap-matrix image of the folded tail (conv_f16x3.hip) """
+    _dev_f32(w, "tail weight")
+    assert tuple(w.shape) == (4, 64, 3, 3)
+    if _CHECK_RANGE:
+        _check_f16_weight_range(w, "folded decoder tail")
+    out = torch.empty(lib().tocvp_tail_taps_f16x3_bytes() // 2, device=w.device, dtype=torch.float16)
+    _check(lib().tocvp_pack_tail_taps_f16x3(_ptr(w.contiguous()), _ptr(out), _stream()), "tocvp_pack_tail_taps_f16x3")
+    return out
+
+
+def conv5x5_dec_f16x3_tail(x, wf, bias, taps, relu=True, out=None, pm_in=False, planes=False):
+    """
+    Last hidden decoder layer with the tail folded into its epilogue (tocvp_conv5x5_dec_f16x3_tail_f32): returns the
+    (n, 36, H, W) tap products; ``x`` as for conv5x5_dec_f16x3 (NHWC, or pass-major / operand planes with pm_in).
+    """
+    n, H, W, Cin = x.shape
+    assert x.is_contiguous() and Cin == 64
+    planes = bool(planes) and bool(pm_in) and not _CHECK_RANGE and not _CONV_PERSISTENT   # as the producing call decided
+    if _CHECK_RANGE:
+        _check_f16_range(absmax(x), "conv5x5_dec_f16x3 (folded tail) input")
+    if out is None:
+        out = torch.empty((n, 36, H, W), device=x.device, dtype=torch.float32)
+
+    def run():
+        _check(lib().tocvp_conv5x5_dec_f16x3_tail_f32(_ptr(x), _ptr(wf), _ptr(bias), _ptr(taps), _ptr(out), n, H, W,
+                                                      int(bool(relu)), int(bool(pm_in)) | (8 if planes else 0),
+                                                      _stream()), "tocvp_conv5x5_dec_f16x3_tail_f32")
+    if TIMER is not None:
+        TIMER.wrap("conv5x5_64_64", n, run)
+    else:
+        run()
+    return out
+
+
+def dec_tail_sum(products, bias, F, K, out=None):
+    """ tap products (F*K, 36, H, W) -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W) """
+    n, T, H, W = products.shape
+    assert n == F * K and T == 36 and products.is_contiguous()
+    dev = products.device
+    if out is not None:
+        imgs, recons, masks = out
+        assert imgs.is_contiguous() and recons.is_contiguous() and masks.is_contiguous()
+    else:
+        imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
+        recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
+        masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
+    _check(lib().tocvp_dec_tail_sum_f32(_ptr(products), _ptr(bias), _ptr(imgs), _ptr(recons), _ptr(masks), F, K, H, W,
+                                        _stream()), "tocvp_dec_tail_sum_f32")
     return imgs, recons, masks
 
 

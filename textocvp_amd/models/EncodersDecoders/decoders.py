@@ -74,6 +74,9 @@ class ConvDecoder(nn.Module):
         self.pass_major = os.environ.get("TOCVP_CONV_PASS_MAJOR", "1") != "0"
         # f16x3 layers hand their activations over as fp16 operand planes (the consumer stages them by LDS-DMA)
         self.conv_planes = os.environ.get("TOCVP_CONV_PLANES", "1") != "0"
+        # the tail Conv2d(64 -> 4, k = 3) folded into the last hidden layer's epilogue (36 tap products per pixel leave
+        # the chip instead of 64 channels; tocvp_dec_tail_sum_f32 adds the nine shifted planes)
+        self.tail_fold = os.environ.get("TOCVP_DEC_TAIL_FOLD", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
@@ -99,6 +102,10 @@ class ConvDecoder(nn.Module):
         conv = self.decoder[i].conv
         return self._derived.get(f"w16{i}", [conv.weight],
                                  lambda: K.split_conv_weights_dec_f16x3(conv.weight))
+
+    def _tail_taps(self):
+        tail = self.decoder[len(self.hidden_dims)]
+        return self._derived.get("tail_taps", [tail.weight], lambda: K.pack_tail_taps_f16x3(tail.weight))
 
     def _collapsed_layer0(self, pos_table):
         """ (cpos (H,W,C0), tapsum (25*C0, D)) for the current weights / position table """
@@ -135,11 +142,12 @@ class ConvDecoder(nn.Module):
         tail = self.decoder[n_hidden]
         fpc = max(1, self.max_slot_images // Ks)             # frames per chunk
         bufs = [None, None]
+        prod = None
         for f0 in range(0, F_, fpc):
             f1 = min(F_, f0 + fpc)
             n = (f1 - f0) * Ks
             S = K.linear(slots[f0:f1].reshape(n, D), tapsum).reshape(n, 25, C0)
-            x, which, pm_prev = None, 0, False
+            x, which, pm_prev, folded = None, 0, False, False
             for i in range(1, n_hidden):
                 conv = self.decoder[i].conv
                 co = conv.weight.shape[0]
@@ -149,6 +157,17 @@ class ConvDecoder(nn.Module):
                     bufs[which] = out
                 c64 = conv.weight.shape[0] == 64 and conv.weight.shape[1] == 64
                 split = self.conv_precision in ("bf16x3", "f16f8", "f16x3") and c64
+                fold = (self.tail_fold and i == n_hidden - 1 and i > 1 and self.conv_precision == "f16x3" and c64
+                        and W % 64 == 0 and H % 8 == 0 and tuple(tail.weight.shape) == (4, 64, 3, 3))
+                if fold:
+                    # last hidden layer: the tail's tap products leave its epilogue, the tail only sums them
+                    if prod is None or prod.shape[0] != n:
+                        prod = torch.empty((n, 36, H, W), device=dev, dtype=torch.float32)
+                    planes_in = self.conv_planes and pm_prev and H * W <= 16384
+                    K.conv5x5_dec_f16x3_tail(x, self._split16(i), conv.bias, self._tail_taps(), relu=True, out=prod,
+                                             pm_in=pm_prev, planes=planes_in)
+                    folded = True
+                    break
                 if self.conv_precision in ("f16f8", "f16x3") and c64 and W % 64 == 0 and H % 8 == 0:
                     # consecutive tiled layers hand their activations over in the pass-major layout
                     nxt = self.decoder[i + 1].conv if i + 1 < n_hidden else None
@@ -172,8 +191,11 @@ class ConvDecoder(nn.Module):
                 else:
                     x = K.conv5x5(x, self._packed(i), conv.bias, relu=True, out=out)
                 which ^= 1
-            K.dec_tail(x, tail.weight, tail.bias, f1 - f0, Ks,
-                       out=(imgs[f0:f1], recons[f0:f1], masks[f0:f1]))
+            if folded:
+                K.dec_tail_sum(prod, tail.bias, f1 - f0, Ks, out=(imgs[f0:f1], recons[f0:f1], masks[f0:f1]))
+            else:
+                K.dec_tail(x, tail.weight, tail.bias, f1 - f0, Ks,
+                           out=(imgs[f0:f1], recons[f0:f1], masks[f0:f1]))
         return imgs, recons, masks
 
     def forward(self, x):
