@@ -930,7 +930,9 @@ def conv5x5_dec_f16x3_tail(x, wf, bias, taps, relu=True, out=None, pm_in=False, 
                                                       int(bool(relu)), int(bool(pm_in)) | (8 if planes else 0),
                                                       _stream()), "tocvp_conv5x5_dec_f16x3_tail_f32")
     if TIMER is not None:
-        TIMER.wrap("conv5x5_64_64", n, run)
+        # work units of the launch timer are slot images of 0.839 GFLOP (one 5 x 5 layer); the folded tail adds its
+        # 2 x 36 x 64 x H x W = 18.9 MFLOP per 64 x 64 slot image to this launch
+        TIMER.wrap("conv5x5_64_64", n * (1.0 + (2.0 * 36 * 64) / (2.0 * 25 * 64 * 64)), run)
     else:
         run()
     return out
