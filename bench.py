@@ -496,7 +496,8 @@ def main():
                         "share_of_step_time": round(conv["total_ms"] / 1e3 / elapsed_no, 3),
                         "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the second timed region: the "
                                 "same K steps without the decode / rollout overlap, value_no_overlap; "
-                                "algorithmic 0.839 GFLOP per slot image and layer); frac prices ALGORITHMIC flops "
+                                "algorithmic 0.839 GFLOP per slot image and layer, + 0.019 in the last layer, whose epilogue "
+                                "also applies the decoder tail's taps); frac prices ALGORITHMIC flops "
                                 "against the dense f16 peak, frac_executed_mfma counts the matrix products the "
                                 "split arithmetic really issues"}
             rooflines.append(roofline)
