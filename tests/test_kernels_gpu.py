@@ -734,6 +734,7 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
     """
     import ctypes
     k = _k()
+    monkeypatch.setattr(k, "_GEMM_P2", True)                    # the persistent planes kernel is opt-in
     monkeypatch.setattr(k, "_GEMM_P2_MIN_ROWS", 1)              # every plane-input product on the planes kernel
     x = rnd("p3x", (M, Kd), "normal")
     w = rnd("p3w", (N, Kd), "uniform", Kd ** -0.5)

@@ -407,7 +407,9 @@ class gemm_precision:
 
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
-_GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "1") != "0"    # all-DMA planes GEMM for plane inputs with N % 256 == 0
+# all-DMA persistent planes GEMM (gemm_f16p.hip) for plane inputs with N % 256 == 0: opt-in (TOCVP_GEMM_P2=1); by
+# default plane inputs go to the in-loop kernel's plane-input form, which shares a CU with the decoder's workgroups
+_GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
 _GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).

@@ -22,8 +22,8 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # Activations that only feed GEMMs can leave their producer (LayerNorm, attention and GEMM epilogues) as fp16
 # operand planes (the bytes of the fp32 tensor); a GEMM fed with planes runs the persistent all-DMA planes kernel
 # (gemm_f16p.hip, planes3: no split in the k-loop, both operands through LDS, 256 x 256 tiles).  TOCVP_PRESPLIT:
-#   "0" (default)  never;
-#   "wide"         only where the consuming GEMM is at least 1536 columns wide (qkv, MLP up-projections);
+#   "0"            never;
+#   "wide" (default) only where the consuming GEMM is at least 1536 columns wide (qkv, MLP up-projections);
 #   "1"            everywhere the shapes allow.
 # Round 3 (planes3), isolated, 38400 rows, dense random operands, planes3 vs the in-loop-split kernel: 2048x512
 # 255-280 vs 380-400 us, 1536x512 205-227 vs 239 us, 512x2048 288 vs 290 us, 512x512 107 vs 80 us.  IN the rollout
@@ -33,8 +33,14 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # kernel with 128 KB of LDS cannot share a CU with the decoder's workgroups, the 36 KB in-loop-split kernel can),
 # 3467 vs 3449 frames/s (+0.5 %) without the overlap -> neutral, the in-kernel split stays the default
 # (profiles/r03_gemm_planes3.md).
-_PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "0")
+# End of round 3: "wide" with the planes consumed by the IN-LOOP kernel's plane-input form (gemm_bf16_wfrag_kernel
+# ASPLIT: 36 KB of LDS, two workgroups per CU, no split instructions in its k-loop; TOCVP_GEMM_P2=0, now the default)
+# is the default: same arithmetic (the producer makes the split the consumer would make), +1.5 % on the step with
+# the decoder overlapped (3694-3704 -> 3754-3759 frames/s, three alternations on one box) and neutral without the
+# overlap (3637-3640 vs 3640-3644): the rollout's GEMMs leave the vector ALUs to the decoder's staging.
+_PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "wide")
 _PRESPLIT_MIN_N = 1536
+_PRESPLIT_MIN_ROWS = 16384    # B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
 # LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
 _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
@@ -51,6 +57,10 @@ class TextKV:
 
 
 def _ln(x, ln, add=None, split=0):
+    # planes only for the many-row products: the skinny GEMMs of small batches take fp32 input (split-K over idle CUs,
+    # 64-deep k-tiles), mid-size ones measured slower with planes -- and small-batch results stay what they were
+    if split and x.numel() // x.shape[-1] <= _PRESPLIT_MIN_ROWS:
+        split = 0
     return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add, split=split)
 
 
