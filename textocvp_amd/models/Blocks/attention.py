@@ -7,6 +7,7 @@ fp32-MFMA GEMMs with fused bias / ReLU / residual epilogues, one-wave-per-row La
 flash-style fp32-MFMA attention and the location-streaming slot-attention iteration.
 """
 
+import math
 import os
 
 import torch
@@ -39,6 +40,10 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # the decoder overlapped (3694-3704 -> 3754-3759 frames/s, three alternations on one box) and neutral without the
 # overlap (3637-3640 vs 3640-3644): the rollout's GEMMs leave the vector ALUs to the decoder's staging.
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "wide")
+# ... and the MLP's hidden activation leaves the up-projection's epilogue as planes for the down-projection (its 2048-deep
+# k-loop then holds no split instructions): another +0.5 % with the decoder overlapped (3799-3807 -> 3819-3827 frames/s,
+# two alternations), -0.3 % without; same rows threshold; bit-identical
+_PRESPLIT_MLP = os.environ.get("TOCVP_PRESPLIT_MLP", "1") != "0"
 _PRESPLIT_MIN_N = 1536
 _PRESPLIT_MIN_ROWS = 16384    # B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
@@ -82,6 +87,9 @@ def _mlp(x, seq, residual):
     """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
     ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0],
              n_out=seq[2].weight.shape[0])
+    if (_PRESPLIT_MLP and not ns and K.active_nsplit() == 22 and math.prod(tuple(x.shape[:-1])) > _PRESPLIT_MIN_ROWS
+            and all(d % 64 == 0 for d in seq[0].weight.shape + seq[2].weight.shape[:1])):
+        ns = 22                           # the hidden activation leaves the up-projection's epilogue as planes
     h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
     return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
 
