@@ -22,6 +22,17 @@ __all__ = ["forward_eval", "forward_eval_decomp", "psnr_per_frame", "shard_batch
 
 
 _SIDE_STREAMS = {}
+_ENCODE_STREAMS = {}
+_OVERLAP_ENCODE = os.environ.get("TOCVP_OVERLAP_ENCODE", "1") != "0"
+_OVERLAP_ENCODE_MIN_BATCH = int(os.environ.get("TOCVP_OVERLAP_ENCODE_MIN_BATCH", "1"))
+
+
+def _encode_stream(device):
+    key = (device.type, device.index)
+    if key not in _ENCODE_STREAMS:
+        _ENCODE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _ENCODE_STREAMS[key]
+
 
 
 def _side_stream(device):
@@ -57,15 +68,36 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         if changed:
             warnings.warn(f"textocvp_amd: operands outside the fp16-plane range, arithmetic changed: {changed}")
     num_slots, slot_dim = decomp_model.num_slots, decomp_model.slot_dim
-    out_model = decomp_model(mode="decomp", x=videos, num_imgs=num_context + num_preds,
-                             decode=False, **others)
-    slot_history = out_model["slot_history"]
     if overlap_decode is None:
         # on by default at every batch size: same kernels, same arithmetic, bit-identical results
         # (tests: test_decode_overlap_is_bit_identical, test_bench_shape_b128_*).  Below ~96 sequences the rollout
         # cannot fill the chip and the gain is large; at B=128 it is +2-3 %.
         # TOCVP_OVERLAP_DECODE=0 runs the serial order (what bench.py's per-kernel attribution pass uses).
         overlap_decode = os.environ.get("TOCVP_OVERLAP_DECODE", "1") != "0"
+    # The rollout needs the slots of the context frames only; the frames behind them are decomposed for the returned
+    # slot_history alone.  With the overlap on (and a model that can cut its decomposition: SAVi.decomp_frames) they
+    # are decomposed on a third stream while the rollout and the decoder already run -- the same kernels on the same
+    # images, bit-identical (TOCVP_OVERLAP_ENCODE=0: the whole decomposition first, as the reference orders it).
+    core = getattr(decomp_model, "module", decomp_model)
+    n_all = num_context + num_preds
+    rest = None
+    if (overlap_decode and videos.is_cuda and _OVERLAP_ENCODE and hasattr(core, "decomp_frames") and num_preds > 0
+            and not getattr(core, "_range_unchecked", False) and B >= _OVERLAP_ENCODE_MIN_BATCH):
+        main = torch.cuda.current_stream()
+        enc = _encode_stream(videos.device)
+        predicted = core.initializer(batch_size=B, **others)
+        first, state = core.decomp_frames(videos, 0, num_context, predicted)
+        slot_ctx = torch.stack(first, dim=1)                          # (B, num_context, K, D)
+        enc.wait_stream(main)
+        videos.record_stream(enc)
+        state.record_stream(enc)
+        with torch.cuda.stream(enc):
+            later, _ = core.decomp_frames(videos, num_context, n_all, state)
+            rest = torch.stack(later, dim=1)
+        slot_history = slot_ctx                                       # what the rollout reads
+    else:
+        out_model = decomp_model(mode="decomp", x=videos, num_imgs=n_all, decode=False, **others)
+        slot_history = out_model["slot_history"]
     if not (overlap_decode and slot_history.is_cuda):
         pred_slots = predictor(slot_history, **others)
         out_dec = decomp_model(mode="decode",
@@ -96,6 +128,11 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
             recons = recons.reshape(B * num_preds, *recons.shape[2:])
         recons_imgs = imgs.reshape(B * num_preds, C, H, W)
         pred_imgs = imgs.clamp(0, 1)
+    if rest is not None:                                              # join the decomposition of the later frames
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(_encode_stream(videos.device))
+        rest.record_stream(cur)
+        slot_history = torch.cat([slot_history, rest], dim=1)
     targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)
     # recons / recons_imgs: SAVi.decode's per-slot and composited frames, (B*P, ...) and UNclamped
     return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,

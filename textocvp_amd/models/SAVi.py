@@ -98,28 +98,8 @@ class SAVi(nn.Module, RangeGuard):
         require_inference(self)
         B = x.shape[0]
         T = num_imgs
-        dev = self.slot_attention.to_q.weight.device
-        x = x.to(dev)
         predicted = self.initializer(batch_size=B, **kwargs)
-
-        # time-major copy of the frames: (T, B, C, H, W), so that frame t of all samples is one
-        # contiguous (B, N, 2D) k/v block for the slot-attention kernel
-        frames = x[:, :T].transpose(0, 1).contiguous()
-        chunk = max(1, self.max_encode_images // max(B, 1))
-        sa = self.slot_attention
-        history = []
-        for t0 in range(0, T, chunk):
-            t1 = min(T, t0 + chunk)
-            kv = self._encode_kv(frames[t0:t1].reshape((t1 - t0) * B, *frames.shape[2:]))
-            if isinstance(kv, K.SplitAct):                      # fp16 operand planes of the (t1 - t0) * B images
-                kv = K.SplitAct(kv.planes, (t1 - t0, B) + tuple(kv.shape[1:]))
-            else:
-                kv = kv.reshape(t1 - t0, B, kv.shape[-2], kv.shape[-1])
-            for t in range(t0, t1):
-                n_it = sa.num_iters_first if t == 0 else sa.num_iters
-                slots = sa.iterate(sa.frame_kv(kv, t - t0, t1 - t0), predicted, n_it)
-                predicted = self.transition_module(slots)
-                history.append(slots)
+        history, _ = self.decomp_frames(x, 0, T, predicted)
         slot_history = torch.stack(history, dim=1)                      # (B, T, K, D)
 
         if decode:
@@ -132,6 +112,40 @@ class SAVi(nn.Module, RangeGuard):
             recons_imgs = recons_objs = masks = torch.empty((0, T))
         return {"recons_imgs": recons_imgs, "recons_objs": recons_objs, "masks": masks,
                 "slot_history": slot_history}
+
+    def decomp_frames(self, x, t_begin, t_end, predicted):
+        """
+        The recurrent part of forward_decomp for frames t_begin .. t_end - 1 of x (B, L, C, H, W): encode (batched
+        over up to ``max_encode_images`` images), slot-attention iterations (``num_iters_first`` on frame 0), transition.
+        ``predicted`` (B, K, D) = the initialiser's slots (t_begin = 0) or the transition output of frame t_begin - 1.
+        Returns ([slots of every frame], predicted for frame t_end): a decomposition may be cut at any frame and
+        continued later -- evaluator.forward_eval encodes the context frames, starts the rollout and decomposes the
+        remaining frames on another stream.  Every image goes through the same kernels whatever the cut.
+        """
+        require_inference(self)
+        B = x.shape[0]
+        dev = self.slot_attention.to_q.weight.device
+        x = x.to(dev)
+        # time-major copy of the frames: (T, B, C, H, W), so that frame t of all samples is one
+        # contiguous (B, N, 2D) k/v block for the slot-attention kernel
+        frames = x[:, t_begin:t_end].transpose(0, 1).contiguous()
+        T = t_end - t_begin
+        chunk = max(1, self.max_encode_images // max(B, 1))
+        sa = self.slot_attention
+        history = []
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            kv = self._encode_kv(frames[t0:t1].reshape((t1 - t0) * B, *frames.shape[2:]))
+            if isinstance(kv, K.SplitAct):                      # fp16 operand planes of the (t1 - t0) * B images
+                kv = K.SplitAct(kv.planes, (t1 - t0, B) + tuple(kv.shape[1:]))
+            else:
+                kv = kv.reshape(t1 - t0, B, kv.shape[-2], kv.shape[-1])
+            for t in range(t0, t1):
+                n_it = sa.num_iters_first if t_begin + t == 0 else sa.num_iters
+                slots = sa.iterate(sa.frame_kv(kv, t - t0, t1 - t0), predicted, n_it)
+                predicted = self.transition_module(slots)
+                history.append(slots)
+        return history, predicted
 
     # ------------------------------------------------------------------------------------------
     def _encode_feats(self, imgs):
