@@ -408,7 +408,8 @@ class gemm_precision:
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
 # all-DMA persistent planes GEMM (gemm_f16p.hip) for plane inputs with N % 256 == 0: opt-in (TOCVP_GEMM_P2=1); by
-# default plane inputs go to the in-loop kernel's plane-input form, which shares a CU with the decoder's workgroups
+# default plane inputs go to the two-workgroups-per-CU planes kernel of gemm_bf16.hip (gemm_f16_planes_kernel; small
+# shapes: the in-loop kernel's ASPLIT form), which shares a CU with the decoder's workgroups
 _GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
 _GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):

@@ -34,8 +34,8 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # kernel with 128 KB of LDS cannot share a CU with the decoder's workgroups, the 36 KB in-loop-split kernel can),
 # 3467 vs 3449 frames/s (+0.5 %) without the overlap -> neutral, the in-kernel split stays the default
 # (profiles/r03_gemm_planes3.md).
-# End of round 3: "wide" with the planes consumed by the IN-LOOP kernel's plane-input form (gemm_bf16_wfrag_kernel
-# ASPLIT: 36 KB of LDS, two workgroups per CU, no split instructions in its k-loop; TOCVP_GEMM_P2=0, now the default)
+# End of round 3: "wide" with the planes consumed by the TWO-workgroups-per-CU planes kernel of gemm_bf16.hip
+# (gemm_f16_planes_kernel: A planes by LDS-DMA, no split instructions in its k-loop; TOCVP_GEMM_P2=0, now the default)
 # is the default: same arithmetic (the producer makes the split the consumer would make), +1.5 % on the step with
 # the decoder overlapped (3694-3704 -> 3754-3759 frames/s, three alternations on one box) and neutral without the
 # overlap (3637-3640 vs 3640-3644): the rollout's GEMMs leave the vector ALUs to the decoder's staging.
