@@ -512,8 +512,10 @@ def main():
                 ns = int(name.split("_")[1][5:])
                 mode, gu = GEMM_UNITS.get(ns, ("split", 3))
                 tf = g["units"] / g["total_ms"] / 1e9
-                rooflines.append({"bound": "mfma", "kernel": f"gemm_bf16_wfrag_kernel ({mode}), predictor GEMM "
-                                  f"{name.split('_')[2]} (M x N x K), the shape with the largest total time",
+                rooflines.append({"bound": "mfma", "kernel": f"predictor GEMM ({mode}) "
+                                  f"{name.split('_')[2]} (M x N x K), the shape with the largest total time: "
+                                  "gemm_f16_planes_kernel where the activation arrives as fp16 operand planes (LayerNorm "
+                                  "/ up-projection epilogue), gemm_bf16_wfrag_kernel (in-loop split) otherwise",
                                   "achieved": round(tf, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tf / F16_MFMA_PEAK_TFLOPS, 4), "matrix_units_per_product": gu,
                                   "frac_executed_mfma": round(gu * tf / F16_MFMA_PEAK_TFLOPS, 4),
