@@ -330,6 +330,14 @@ int tocvp_conv5x5_dec_f16x3_tail_f32(const float* x, const void* wf, const float
                                      float* products, int nimg, int H, int W, int relu, int layout, void* stream);
 int tocvp_dec_tail_sum_f32(const float* products, const float* bias, float* recons_imgs, float* recons, float* masks,
                            int F, int K, int H, int W, void* stream);
+/* Placed form (round 4): frame f of the launch is written at recons_imgs + f * img_fs, recons + f * rec_fs,
+ * masks + f * mask_fs (strides in floats, at least one frame each), so a per-step decode of B frames lands directly at
+ * rows b * P + t of the evaluator's (B * P, ...) results (05_evaluate_predictor.py:88-96 reshapes them from one decode
+ * call; here they are never stacked or copied).  clamped_imgs (nullable, same stride as recons_imgs) also receives
+ * clamp(recons_imgs, 0, 1) -- the evaluator's pred_imgs (:93) -- with torch.clamp's NaN behaviour. */
+int tocvp_dec_tail_sum_placed_f32(const float* products, const float* bias, float* recons_imgs, float* recons,
+                                  float* masks, float* clamped_imgs, long img_fs, long rec_fs, long mask_fs, int F,
+                                  int K, int H, int W, void* stream);
 
 /* tap-sum matrices of the collapsed decoder layer 0:
  *   out[cls=(cy*5+cx), co, ci] = sum over taps (dy,dx) valid for border class (cy,cx) of
@@ -347,6 +355,15 @@ int tocvp_dec_tapsum_f32(const float* w, float* out, int Cout, int Cin, void* st
 int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias, float* recons_imgs,
                        float* recons, float* masks, int F, int K, int H, int W, int Cin,
                        void* ws, size_t ws_bytes, void* stream);
+/* placed form: output frame strides + optional clamped frames, as tocvp_dec_tail_sum_placed_f32 */
+int tocvp_dec_tail_placed_f32(const float* x, const float* w, const float* bias, float* recons_imgs, float* recons,
+                              float* masks, float* clamped_imgs, long img_fs, long rec_fs, long mask_fs, int F, int K,
+                              int H, int W, int Cin, void* ws, size_t ws_bytes, void* stream);
+
+/* dst (rows, row_len) contiguous = clamp(src, 0, 1) over rows of row_len floats that lie src_row_stride floats apart
+ * (row_len, src_row_stride % 4 == 0, 16-byte aligned); NaN stays NaN like torch.clamp.  The evaluator's
+ * targets = videos[:, ctx : ctx + P].clamp(0, 1) (05_evaluate_predictor.py:95) in one pass. */
+int tocvp_clamp01_rows_f32(const float* src, long src_row_stride, float* dst, long rows, long row_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Text-encoder front end (text_encoders.py:89-103): token + position embedding, LayerNorm

@@ -280,6 +280,33 @@ def parity_fixtures(out_dir):
 
 
 @torch.no_grad()
+def long_caption_fixtures(out_dir):
+    """
+    Captions longer than 16 tokens (the text encoder admits 50, text_encoders.py:36, and pads to the longest caption of
+    the batch, :171-175; padded positions take part in the cross-attention, attention.py:303-319): e2e config-1 shapes
+    (K=7, B=2, 1 seed + 4 preds) on the "undamped" SAVi family, two caption batches -- lengths (24, 40) padded to 40,
+    and (50, 17) padded to the 50-token maximum.  Stored per batch: tokens, lengths, pred_slots, the rendered frames
+    (unclamped, full resolution), the masks of sample 0 and the argmax_K(masks) map of every frame.
+    """
+    savi, wrapper = build_reference(num_slots=7, num_context=1, num_preds=4, savi_family="undamped")
+    videos = synth.synth_videos(2, 5, seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    fx = {}
+    for tag, lens in (("l40", [24, 40]), ("l50", [50, 17])):
+        tokens, lengths = synth.synth_captions(2, max_len=max(lens), lengths=lens, seed=7)
+        sh, ps, pi, od = forward_eval(savi, wrapper, videos, tokens, lengths, noise, 1, 4)
+        fx[f"{tag}_tokens"], fx[f"{tag}_lengths"] = tokens.numpy(), lengths.numpy()
+        fx[f"{tag}_pred_slots"] = ps.numpy()
+        fx[f"{tag}_recons_imgs"] = od["recons_imgs"].numpy()
+        fx[f"{tag}_masks_s0"] = od["masks"][:4].numpy()
+        fx[f"{tag}_masks_argmax"] = od["masks"].argmax(dim=1).to(torch.uint8).numpy()
+        if tag == "l40":
+            fx["slot_history"] = sh.numpy()
+    np.savez(os.path.join(out_dir, "long_captions_k7.npz"), **fx)
+    print("long_captions_k7:", {k: v.shape for k, v in fx.items()})
+
+
+@torch.no_grad()
 def decomp_fixtures(out_dir):
     """
     Decomposition-only evaluation (03_evaluate_decomp_model.py:22-46): ``model(x=videos, num_imgs=L)`` with
@@ -445,7 +472,8 @@ def manifest(out_dir):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "decomp", "uncond", "dinosaur", "t5", "train"]
+    what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "longcap", "decomp", "uncond", "dinosaur", "t5",
+                            "train"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -454,6 +482,8 @@ if __name__ == "__main__":
         e2e_fixtures(HERE)
     if "parity" in what:
         parity_fixtures(HERE)
+    if "longcap" in what:
+        long_caption_fixtures(HERE)
     if "decomp" in what:
         decomp_fixtures(HERE)
     if "uncond" in what:

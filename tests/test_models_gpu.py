@@ -245,6 +245,31 @@ def test_e2e_config2_against_reference_golden(k30):
 
 @torch.no_grad()
 @torch.no_grad()
+@pytest.mark.parametrize("tag", ["l40", "l50"])
+def test_e2e_long_captions_against_reference_golden(tag):
+    """
+    Captions beyond 16 tokens (up to the text encoder's 50, text_encoders.py:36; padded to the longest of the batch,
+    padded positions attend, attention.py:303-319): a whole rollout + decode against the reference's own output on the
+    "undamped" SAVi family (O(1) RGB head), lengths (24, 40) and (50, 17).  1e-4 on slots and every rendered pixel,
+    identical slot-index maps.
+    """
+    g = load_golden("long_captions_k7.npz")
+    savi, pred = build(7, 4, savi_family="undamped")
+    videos = synth.synth_videos(2, 5, seed=0)
+    noise = synth.synth_noise(2, 7, 128, seed=1)
+    tokens, lengths = torch.from_numpy(g[f"{tag}_tokens"]), torch.from_numpy(g[f"{tag}_lengths"])
+    out = forward_eval(savi, pred, gpu(videos), 1, 4, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+                       init_noise=noise)
+    errs = {"slot_history": max_abs(out["slot_history"].cpu(), g["slot_history"]),
+            "pred_slots": max_abs(out["pred_slots"].cpu(), g[f"{tag}_pred_slots"]),
+            "recons_imgs": max_abs(out["recons_imgs"].cpu(), g[f"{tag}_recons_imgs"]),
+            "masks_s0": max_abs(out["masks"][:4].cpu(), g[f"{tag}_masks_s0"])}
+    print(f"long captions {tag} (lengths {lengths.tolist()}):", {k_: f"{v:.2e}" for k_, v in errs.items()})
+    assert all(v < 1e-4 for v in errs.values()), errs
+    assert_same_slot_assignment(out["masks"], g[f"{tag}_masks_argmax"], f"e2e long captions {tag} (K=7, undamped)")
+
+
+@torch.no_grad()
 def test_fp16_plane_range_check(k7, monkeypatch):
     """ TOCVP_CHECK_RANGE: every fp16-plane kernel on the path sees operands inside |x| < 255 on the
     synthetic model, and an out-of-range activation is reported instead of saturating silently """
@@ -288,6 +313,43 @@ def test_calibrate_precision_moves_out_of_range_modules():
     # an in-range model is left alone
     savi2, pred2 = build(7, 4)
     assert calibrate_precision(savi2, pred2, videos, 1, 4, **kw) == {}
+
+
+@pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32", reason="all-fp32 mode has no fp16-plane modules")
+@torch.no_grad()
+def test_checked_pass_sees_the_activations_that_only_exist_as_operand_planes(monkeypatch):
+    """
+    Two activations never reach HBM as fp32 on the default path: the decoder's last hidden layer (its epilogue feeds
+    the folded tail with fp16 planes) and the predictor MLP's hidden layer (the up-projection's epilogue writes the
+    planes the down-projection reads).  A checkpoint that is in range everywhere EXCEPT there must still be caught
+    by the checked pass: it runs those two hand-overs in fp32, verifies them, and moves the owner to its fallback.
+    """
+    from textocvp_amd import kernels as K
+    from textocvp_amd.models.Blocks import attention as A
+    from textocvp_amd.setup_model import calibrate_precision
+    videos = gpu(synth.synth_videos(2, 5, seed=0))
+    tokens, lengths = synth.synth_captions(2, max_len=12, lengths=[9, 12], seed=0)
+    kw = dict(caption_tokens=gpu(tokens), caption_lengths=gpu(lengths),
+              init_noise=synth.synth_noise(2, 7, 128, seed=1))
+    # (a) decoder: only the LAST hidden layer's output is large (its input, layer 2's output, stays small)
+    savi, pred = build(7, 4)
+    assert savi.decoder.tail_fold and savi.decoder.conv_precision == "f16x3"
+    last = savi.decoder.decoder[len(savi.decoder.hidden_dims) - 1].conv
+    last.bias.add_(400.0)                                            # relu(y3) ~ 400 > 255.9
+    dslots = gpu(synth.synth_tensor("unit.dec_slots", (2, 7, 128), "normal"))
+    with K.check_range(True):
+        with pytest.raises(K.TocvpRangeError, match="last hidden activation") as ei:
+            savi(mode="decode", slots=dslots)
+    assert ei.value.owner == (savi.decoder, "conv_precision")
+    assert calibrate_precision(savi, pred, videos, 1, 4, **kw) == {("ConvDecoder", "conv_precision"): "bf16x3"}
+    # (b) predictor: only the MLP's hidden activation is large; planes forced on at this small row count
+    monkeypatch.setattr(A, "_PRESPLIT_MIN_ROWS", 0)
+    savi, pred = build(7, 4)
+    blk = pred.predictor.predictor[0]
+    blk.mlp[0].bias.add_(400.0)                                      # relu(hidden) ~ 400
+    blk.mlp[2].weight.mul_(1e-3)                                     # keeps everything downstream in range
+    assert calibrate_precision(savi, pred, videos, 1, 4, **kw) == {
+        (type(pred.predictor).__name__, "gemm_precision"): "bf16x6"}
 
 
 @pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32", reason="all-fp32 mode has no fp16-plane modules")
@@ -337,8 +399,21 @@ def test_decode_overlap_is_bit_identical(k7):
     noise = synth.synth_noise(2, 7, 128, seed=5)
     outs = [forward_eval(savi, pred, videos, 2, 4, overlap_decode=ov, caption_tokens=gpu(tokens),
                          caption_lengths=gpu(lengths), init_noise=noise) for ov in (False, True)]
-    for key in ("slot_history", "pred_slots", "pred_imgs", "masks"):
+    for key in ("slot_history", "pred_slots", "pred_imgs", "masks", "recons", "recons_imgs", "targets"):
         assert torch.equal(outs[0][key], outs[1][key]), key
+    # round 4: the tail kernel places every decode straight into the (B * P, ...) results and writes the clamped
+    # frames itself -- it must give what ONE plain decode call + reshape + torch clamp give (05_evaluate_predictor.py:88-96)
+    o = outs[1]
+    plain = savi(mode="decode", slots=o["pred_slots"].reshape(2 * 4, 7, 128))
+    for key in ("recons_imgs", "recons", "masks"):
+        assert torch.equal(plain[key], o[key]), key
+    assert torch.equal(plain["recons_imgs"].view(2, 4, 3, 64, 64).clamp(0, 1), o["pred_imgs"])
+    assert torch.equal(videos[:, 2:6].clamp(0, 1), o["targets"])
+    bad = videos.clone()
+    bad[0, 3, 1, 5, 7], bad[1, 2, 0, 0, 0], bad[1, 5, 2, 63, 63] = float("nan"), -0.25, 1.5
+    from textocvp_amd import kernels as K
+    got, want = K.clamp01_rows(bad[:, 2:6]), bad[:, 2:6].clamp(0, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0))
 
 
 def test_e2e_against_oracle_fresh_inputs(k7):
@@ -525,6 +600,44 @@ def test_rollout_options_against_oracle():
         assert max_abs(got.cpu(), ref) < 1e-4, f"teacher_force={tf}"
         got2 = pred(hist, num_preds=2, caption_tokens=gpu(tokens), caption_lengths=gpu(lengths))
         assert max_abs(got2.cpu(), ref[:, :2]) < 1e-4
+
+
+@torch.no_grad()
+def test_forward_eval_with_teacher_forcing_reads_the_whole_history():
+    """
+    A wrapper with teacher_force=True reads slot_history[:, num_context + t] inside the rollout
+    (predictor_wrapper.py:74-82; the reference applies the config value in eval mode too), and a wrapper whose
+    own num_context is larger than the evaluator's reads more context frames.  forward_eval must then hand the
+    predictor the FULL decomposition instead of the context-only cut of its overlapped-encode branch
+    (evaluator._reads_context_only), and equal the serial order bit for bit and the oracle at the bar.
+    """
+    from textocvp_amd.evaluator import _reads_context_only
+    exp = default_exp_params(num_slots=7, num_context=2, num_preds=3, input_buffer_size=4)
+    exp["prediction_params"]["teacher_force"] = True
+    savi = setup_model(exp["model"]).eval()
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(savi, prefix="savi.")
+    synth.fill_module_(pred, prefix="pred.")
+    videos = synth.synth_videos(2, 5, seed=51)
+    tokens, lengths = synth.synth_captions(2, max_len=9, lengths=[9, 5], seed=52)
+    noise = synth.synth_noise(2, 7, 128, seed=53)
+    ssd = {k: v.clone() for k, v in savi.state_dict().items()}
+    psd = {k: v.clone() for k, v in pred.state_dict().items()}
+    hist_ref = O.savi_decomp(ssd, videos, noise, 5)
+    ref = O.rollout(psd, hist_ref, tokens, lengths, 2, 3, buffer_size=4, teacher_force=True)
+    savi, pred = savi.to(DEV), pred.to(DEV)
+    assert not _reads_context_only(pred, 2)
+    kw = dict(caption_tokens=gpu(tokens), caption_lengths=gpu(lengths), init_noise=noise)
+    outs = [forward_eval(savi, pred, gpu(videos), 2, 3, overlap_decode=ov, **kw) for ov in (False, True)]
+    for key in ("slot_history", "pred_slots", "pred_imgs", "masks"):
+        assert torch.equal(outs[0][key], outs[1][key]), key
+    assert max_abs(outs[1]["pred_slots"].cpu(), ref) < 1e-4
+    assert max_abs(outs[1]["slot_history"].cpu(), hist_ref) < 1e-4
+    # without teacher forcing the cut is taken -- unless the wrapper itself wants more context than the evaluator
+    exp["prediction_params"]["teacher_force"] = False
+    assert _reads_context_only(pred, 2) and not _reads_context_only(pred, 1)
+    out = forward_eval(savi, pred, gpu(videos), 1, 3, overlap_decode=True, **kw)     # wrapper context 2 > 1
+    assert out["pred_slots"].shape == (2, 3, 7, 128)
 
 
 @torch.no_grad()

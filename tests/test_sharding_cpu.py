@@ -12,7 +12,15 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from textocvp_amd.evaluator import gather_metrics, psnr_per_frame, shard_batches
+from textocvp_amd.evaluator import gather_metrics, shard_batches
+
+
+def psnr_per_frame(preds, targets, eps=1e-8):
+    """ (B, P, C, H, W) x2 -> (B, P) PSNR, piqa 1.2.2's 10*log10(1 / (mse + eps)) (lib/metrics.py:181-212): a plain
+    torch stand-in for the metric rows, so that the gather has a real payload (the product's metric is
+    textocvp_amd.metrics / tocvp_psnr_ssim_f32 on the GPU) """
+    mse = ((preds - targets) ** 2).flatten(2).mean(dim=-1)
+    return 10.0 * torch.log10(1.0 / (mse + eps))
 
 
 def _free_port():

@@ -28,6 +28,9 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // row of accumulator register r for lane-half h (32x32 MFMA C/D layout)
+// torch.clamp(x, 0, 1): NaN stays NaN (both comparisons are false for it)
+__device__ __forceinline__ float tocvp_clamp01(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // butterfly reductions over the 32 lanes of one wave half (lanes l and l^32 stay separate)

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256, 3) void dec_tail_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ recons_imgs,
                                                           float* __restrict__ recons,
-                                                          float* __restrict__ masks, int F, int K, int H,
+                                                          float* __restrict__ masks, float* __restrict__ clamped,
+                                                          long img_fs, long rec_fs, long mask_fs, int F, int K, int H,
                                                           int W) {
+    // frame f lands at recons_imgs + f img_fs, recons + f rec_fs, masks + f mask_fs (floats), as in dec_tail_sum_kernel
     __shared__ __attribute__((aligned(16))) float in_s[DT_IH * DT_IW * DT_CS];
     const int t = threadIdx.x;
     // XCD-aware ids: workgroups are dealt round-robin over the 8 XCDs, so the tiles of ONE frame take ids that are
@@ -311,11 +313,11 @@ __global__ __launch_bounds__(256, 3) void dec_tail_kernel(const float* __restric
             }
         }
         if (pass == 1) {
-            float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
+            float* ro = recons + (size_t)f * rec_fs + (size_t)k * 3 * HW + pix;
             ro[0] = acc[0];
             ro[HW] = acc[1];
             ro[2 * HW] = acc[2];
-            masks[((size_t)f * K + k) * HW + pix] = acc[3];          // raw alpha, normalised in place below
+            masks[(size_t)f * mask_fs + (size_t)k * HW + pix] = acc[3];   // raw alpha, normalised in place below
             acc = bv;
         }
     }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void dec_tail_kernel(const float* __restric
     // softmax over slots (exact two-pass, as F.softmax) + compositing.  The raw alphas of this pixel sit in its own
     // `masks` words (written by this thread: no other thread or workgroup touches them), not in 32 KB of LDS -- the
     // halo tile alone leaves room for three workgroups per CU.
-    float* mp = masks + (size_t)f * K * HW + pix;
+    float* mp = masks + (size_t)f * mask_fs + pix;
     float m = -1.0e30f;
     for (int k = 0; k < K; ++k) m = fmaxf(m, mp[(size_t)k * HW]);
     float sum = 0.f;
@@ -333,15 +335,21 @@ __global__ __launch_bounds__(256, 3) void dec_tail_kernel(const float* __restric
     for (int k = 0; k < K; ++k) {
         const float mk = expf(mp[(size_t)k * HW] - m) * inv;
         mp[(size_t)k * HW] = mk;
-        const float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix;
+        const float* ro = recons + (size_t)f * rec_fs + (size_t)k * 3 * HW + pix;
         c0 += ro[0] * mk;
         c1 += ro[HW] * mk;
         c2 += ro[2 * HW] * mk;
     }
-    float* co = recons_imgs + (size_t)f * 3 * HW + pix;
+    float* co = recons_imgs + (size_t)f * img_fs + pix;
     co[0] = c0;
     co[HW] = c1;
     co[2 * HW] = c2;
+    if (clamped) {
+        float* cc = clamped + (size_t)f * img_fs + pix;
+        cc[0] = tocvp_clamp01(c0);
+        cc[HW] = tocvp_clamp01(c1);
+        cc[2 * HW] = tocvp_clamp01(c2);
+    }
 }
 
 // (4, C, 3, 3) -> [tap][c][4] so that the 4 output channels of one (tap, c) are one 16-byte group
@@ -398,13 +406,15 @@ extern "C" int tocvp_conv5x5_in3_f32(const float* x, long long img_stride, const
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias,
-                                  float* recons_imgs, float* recons, float* masks, int F, int K,
-                                  int H, int W, int Cin, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int tocvp_dec_tail_placed_f32(const float* x, const float* w, const float* bias, float* recons_imgs,
+                                         float* recons, float* masks, float* clamped_imgs, long img_fs, long rec_fs,
+                                         long mask_fs, int F, int K, int H, int W, int Cin, void* ws, size_t ws_bytes,
+                                         void* stream) {
     TOCVP_CHECK_ARG(x && w && bias && recons_imgs && recons && masks && ws);
     TOCVP_CHECK_ARG(F >= 0 && F <= 65535 && K > 0 && K <= 32 && Cin == DT_C);
     TOCVP_CHECK_ARG((H % DT_H) == 0 && (W % DT_W) == 0);
     TOCVP_CHECK_ARG(ws_bytes >= (size_t)9 * DT_C * 4 * sizeof(float));
+    TOCVP_CHECK_ARG(img_fs >= 3L * H * W && rec_fs >= 3L * K * H * W && mask_fs >= (long)K * H * W);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(ws)) return TOCVP_EALIGN;
     if (F == 0) return TOCVP_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -413,6 +423,14 @@ extern "C" int tocvp_dec_tail_f32(const float* x, const float* w, const float* b
                        DT_C);
     if (hipGetLastError() != hipSuccess) return TOCVP_ELAUNCH;
     hipLaunchKernelGGL(dec_tail_kernel, dim3((H / DT_H) * (W / DT_W) * ((F + 7) / 8 * 8)), dim3(256), 0, s, x,
-                       static_cast<const float*>(wq), bias, recons_imgs, recons, masks, F, K, H, W);
+                       static_cast<const float*>(wq), bias, recons_imgs, recons, masks, clamped_imgs, img_fs, rec_fs,
+                       mask_fs, F, K, H, W);
     return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_tail_f32(const float* x, const float* w, const float* bias,
+                                  float* recons_imgs, float* recons, float* masks, int F, int K,
+                                  int H, int W, int Cin, void* ws, size_t ws_bytes, void* stream) {
+    return tocvp_dec_tail_placed_f32(x, w, bias, recons_imgs, recons, masks, nullptr, 3L * H * W, 3L * K * H * W,
+                                     (long)K * H * W, F, K, H, W, Cin, ws, ws_bytes, stream);
 }

@@ -862,7 +862,10 @@ __global__ __launch_bounds__(256) void pack_tail_taps_kernel(const float* __rest
 // One thread per pixel, 4 rows x 64 pixels per workgroup; every P value is read once, coalesced along x.
 __global__ __launch_bounds__(256) void dec_tail_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias,
                                                            float* __restrict__ recons_imgs, float* __restrict__ recons,
-                                                           float* __restrict__ masks, int K, int H, int W) {
+                                                           float* __restrict__ masks, float* __restrict__ clamped,
+                                                           long img_fs, long rec_fs, long mask_fs, int K, int H, int W) {
+    // frame f of the launch lands at recons_imgs + f img_fs, recons + f rec_fs, masks + f mask_fs (floats): the
+    // evaluator's per-step decodes write straight into the (B, P, ...) result tensors at their step offset
     const int f = blockIdx.y;
     const int pix_lin = blockIdx.x * 256 + threadIdx.x;
     const size_t HW = (size_t)H * W;
@@ -877,7 +880,8 @@ __global__ __launch_bounds__(256) void dec_tail_sum_kernel(const float* __restri
         ok[t] = yy >= 0 && yy < H && xx >= 0 && xx < W;
         off[t] = ok[t] ? yy * W + xx : pix_lin;
     }
-    float* mp = masks + (size_t)f * K * HW + pix_lin;
+    float* mp = masks + (size_t)f * mask_fs + pix_lin;
+    float* rf = recons + (size_t)f * rec_fs + pix_lin;
     for (int k = 0; k < K; ++k) {
         const float* Pk = P + ((size_t)f * K + k) * 36 * HW;
         float v[4] = {b0, b1, b2, b3};
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(256) void dec_tail_sum_kernel(const float* __restri
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int o = 0; o < 4; ++o) v[o] += ok[t] ? q[4 * t + o] : 0.f;
-        float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix_lin;
+        float* ro = rf + (size_t)k * 3 * HW;
         ro[0] = v[0];
         ro[HW] = v[1];
         ro[2 * HW] = v[2];
@@ -905,15 +909,21 @@ __global__ __launch_bounds__(256) void dec_tail_sum_kernel(const float* __restri
     for (int k = 0; k < K; ++k) {
         const float mk = expf(mp[(size_t)k * HW] - m) * inv;
         mp[(size_t)k * HW] = mk;
-        const float* ro = recons + ((size_t)f * K + k) * 3 * HW + pix_lin;
+        const float* ro = rf + (size_t)k * 3 * HW;
         c0 += ro[0] * mk;
         c1 += ro[HW] * mk;
         c2 += ro[2 * HW] * mk;
     }
-    float* co = recons_imgs + (size_t)f * 3 * HW + pix_lin;
+    float* co = recons_imgs + (size_t)f * img_fs + pix_lin;
     co[0] = c0;
     co[HW] = c1;
     co[2 * HW] = c2;
+    if (clamped) {                                    // the evaluator's .clamp(0, 1) (05_evaluate_predictor.py:93-96)
+        float* cc = clamped + (size_t)f * img_fs + pix_lin;
+        cc[0] = tocvp_clamp01(c0);
+        cc[HW] = tocvp_clamp01(c1);
+        cc[2 * HW] = tocvp_clamp01(c2);
+    }
 }
 
 }  // namespace
@@ -1021,12 +1031,22 @@ extern "C" int tocvp_conv5x5_dec_f16x3_tail_f32(const float* x, const void* wf, 
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_dec_tail_sum_f32(const float* products, const float* bias, float* recons_imgs, float* recons,
-                                      float* masks, int F, int K, int H, int W, void* stream) {
+extern "C" int tocvp_dec_tail_sum_placed_f32(const float* products, const float* bias, float* recons_imgs, float* recons,
+                                             float* masks, float* clamped_imgs, long img_fs, long rec_fs, long mask_fs,
+                                             int F, int K, int H, int W, void* stream) {
     TOCVP_CHECK_ARG(products && bias && recons_imgs && recons && masks);
     TOCVP_CHECK_ARG(F >= 0 && F <= 65535 && K > 0 && H > 0 && W > 0 && (long)H * W < (1L << 30));
+    // frames must not overlap: strides at least one frame of each output
+    TOCVP_CHECK_ARG(img_fs >= 3L * H * W && rec_fs >= 3L * K * H * W && mask_fs >= (long)K * H * W);
     if (F == 0) return TOCVP_OK;
     hipLaunchKernelGGL(dec_tail_sum_kernel, dim3((unsigned)((H * W + 255) / 256), F), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), products, bias, recons_imgs, recons, masks, K, H, W);
+                       static_cast<hipStream_t>(stream), products, bias, recons_imgs, recons, masks, clamped_imgs, img_fs,
+                       rec_fs, mask_fs, K, H, W);
     return tocvp_launch_status();
+}
+
+extern "C" int tocvp_dec_tail_sum_f32(const float* products, const float* bias, float* recons_imgs, float* recons,
+                                      float* masks, int F, int K, int H, int W, void* stream) {
+    return tocvp_dec_tail_sum_placed_f32(products, bias, recons_imgs, recons, masks, nullptr, 3L * H * W, 3L * K * H * W,
+                                         (long)K * H * W, F, K, H, W, stream);
 }

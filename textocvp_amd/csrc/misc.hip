@@ -283,6 +283,19 @@ __global__ __launch_bounds__(256) void slot_init_kernel(const float* __restrict_
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 // max |x| of a tensor as the BIT PATTERN of the (non-negative) float: orders like an unsigned integer, so one
+// dst[r, :] = clamp(src[r * src_rs + :], 0, 1) for rows of row_len floats (row_len % 4 == 0, 16-byte aligned rows):
+// the evaluator's targets = videos[:, ctx : ctx + P].clamp(0, 1) in one pass over a row-strided slice
+__global__ __launch_bounds__(256) void clamp01_rows_kernel(const float* __restrict__ src, long src_rs,
+                                                           float* __restrict__ dst, long row_len4, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long r = i / row_len4, c = i - r * row_len4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + r * src_rs + 4 * c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = tocvp_clamp01(v[u]);
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = v;
+    }
+}
+
 // atomicMax per wave collects it; a NaN anywhere reads as +inf (range checks must not pass on NaN)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     unsigned m = 0;
@@ -450,5 +463,20 @@ extern "C" int tocvp_absmax_f32(const float* x, long n, void* out, void* stream)
     const long want = (n + 255) / 256;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n,
                        static_cast<unsigned*>(out));
+    return tocvp_launch_status();
+}
+
+/* dst (rows, row_len) contiguous = clamp(src rows of row_len floats, src_row_stride floats apart, 0, 1); NaN stays NaN
+ * (torch.clamp).  The evaluator's targets: videos[:, ctx : ctx + P].clamp(0, 1) (05_evaluate_predictor.py:95). */
+extern "C" int tocvp_clamp01_rows_f32(const float* src, long src_row_stride, float* dst, long rows, long row_len,
+                                      void* stream) {
+    TOCVP_CHECK_ARG(src && dst && rows >= 0 && row_len >= 0 && (row_len & 3) == 0 && (src_row_stride & 3) == 0);
+    TOCVP_CHECK_ARG(src_row_stride >= row_len);
+    if (!tocvp_aligned16(src) || !tocvp_aligned16(dst)) return TOCVP_EALIGN;
+    const long total4 = rows * (row_len / 4);
+    if (total4 == 0) return TOCVP_OK;
+    const long want = (total4 + 255) / 256;
+    hipLaunchKernelGGL(clamp01_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, src_row_stride, dst, row_len / 4, total4);
     return tocvp_launch_status();
 }

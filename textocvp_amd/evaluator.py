@@ -18,7 +18,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["forward_eval", "forward_eval_decomp", "psnr_per_frame", "shard_batches", "gather_metrics"]
+__all__ = ["forward_eval", "forward_eval_decomp", "shard_batches", "gather_metrics"]
 
 
 _SIDE_STREAMS = {}
@@ -40,6 +40,23 @@ def _side_stream(device):
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
+
+
+def _reads_context_only(predictor, num_context):
+    """
+    True when the rollout provably reads ``slot_history[:, :num_context]`` and nothing behind it, so the frames behind
+    the context may be decomposed later.  A wrapper with ``teacher_force`` on reads ``slot_history[:, num_context + t]``
+    (predictor_wrapper.py:74-82 -- the reference applies the config value in eval mode too), and a wrapper whose own
+    ``num_context`` exceeds the evaluator's reads more context frames than the cut would hand it.  Anything that is not a
+    recognisable PredictorWrapper gets the full history.
+    """
+    wrapper = getattr(predictor, "module", predictor)
+    params = getattr(wrapper, "exp_params", None)
+    if not isinstance(params, dict) or "prediction_params" not in params:
+        return False
+    if params["prediction_params"].get("teacher_force", False):      # what _rollout re-reads on every call
+        return False
+    return int(getattr(wrapper, "num_context", num_context + 1)) <= num_context
 
 
 @torch.no_grad()
@@ -82,7 +99,8 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     n_all = num_context + num_preds
     rest = None
     if (overlap_decode and videos.is_cuda and _OVERLAP_ENCODE and hasattr(core, "decomp_frames") and num_preds > 0
-            and not getattr(core, "_range_unchecked", False) and B >= _OVERLAP_ENCODE_MIN_BATCH):
+            and not getattr(core, "_range_unchecked", False) and B >= _OVERLAP_ENCODE_MIN_BATCH
+            and _reads_context_only(predictor, num_context)):
         main = torch.cuda.current_stream()
         enc = _encode_stream(videos.device)
         predicted = core.initializer(batch_size=B, **others)
@@ -98,16 +116,36 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
     else:
         out_model = decomp_model(mode="decomp", x=videos, num_imgs=n_all, decode=False, **others)
         slot_history = out_model["slot_history"]
+    # The decoder's tail kernel writes straight into the results the reference reshapes out of ONE decode call
+    # (05_evaluate_predictor.py:88-96): recons_imgs / recons / masks as (B * P, ...) with row b * P + t, and the clamped
+    # frames pred_imgs (B, P, C, H, W) from the same kernel -- no stack, no copy, no elementwise clamp.  Models whose
+    # decode has no ``out`` placement (ExtendedDINOSAUR) keep the stack / clamp form.
+    placed = slot_history.is_cuda and getattr(core, "decode_accepts_out", False)
+    if placed:
+        dev = slot_history.device
+        F_ = B * num_preds
+        recons_imgs = torch.empty((F_, C, H, W), device=dev, dtype=torch.float32)
+        recons = torch.empty((F_, num_slots, C, H, W), device=dev, dtype=torch.float32)
+        masks = torch.empty((F_, num_slots, 1, H, W), device=dev, dtype=torch.float32)
+        pred_imgs = torch.empty((B, num_preds, C, H, W), device=dev, dtype=torch.float32)
+        full = (recons_imgs, recons, masks, pred_imgs.view(F_, C, H, W))
     if not (overlap_decode and slot_history.is_cuda):
         pred_slots = predictor(slot_history, **others)
-        out_dec = decomp_model(mode="decode",
-                               slots=pred_slots.reshape(B * num_preds, num_slots, slot_dim))
-        pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
-        masks, recons, recons_imgs = out_dec["masks"], out_dec.get("recons"), out_dec["recons_imgs"]
+        flat = pred_slots.reshape(B * num_preds, num_slots, slot_dim)
+        if placed:
+            decomp_model(mode="decode", slots=flat, out=full)
+        else:
+            out_dec = decomp_model(mode="decode", slots=flat)
+            pred_imgs = out_dec["recons_imgs"].view(B, num_preds, C, H, W).clamp(0, 1)
+            masks, recons, recons_imgs = out_dec["masks"], out_dec.get("recons"), out_dec["recons_imgs"]
     else:
         main = torch.cuda.current_stream()
         side = _side_stream(slot_history.device)
         per_step = [None] * num_preds
+        if placed:
+            for t_ in full:
+                t_.record_stream(side)
+            step_views = [t_.view(B, num_preds, *t_.shape[1:]) for t_ in full]
 
         def decode_step(t, pred_t):
             ready = torch.cuda.Event()
@@ -115,25 +153,34 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
             pred_t.record_stream(side)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                per_step[t] = decomp_model(mode="decode", slots=pred_t)
-        side.wait_stream(main)                                    # decoder weights / caches are ready
+                if placed:
+                    decomp_model(mode="decode", slots=pred_t, out=tuple(v[:, t] for v in step_views))
+                else:
+                    per_step[t] = decomp_model(mode="decode", slots=pred_t)
+        side.wait_stream(main)                                    # decoder weights / caches / outputs are ready
         pred_slots = predictor(slot_history, step_callback=decode_step, **others)
         main.wait_stream(side)
-        imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
-        masks = torch.stack([d["masks"] for d in per_step], dim=1)
-        masks = masks.reshape(B * num_preds, *masks.shape[2:])
-        recons = None
-        if "recons" in per_step[0]:              # SAVi; ExtendedDINOSAUR returns recons_feats instead
-            recons = torch.stack([d["recons"] for d in per_step], dim=1)
-            recons = recons.reshape(B * num_preds, *recons.shape[2:])
-        recons_imgs = imgs.reshape(B * num_preds, C, H, W)
-        pred_imgs = imgs.clamp(0, 1)
+        if not placed:
+            imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
+            masks = torch.stack([d["masks"] for d in per_step], dim=1)
+            masks = masks.reshape(B * num_preds, *masks.shape[2:])
+            recons = None
+            if "recons" in per_step[0]:              # SAVi; ExtendedDINOSAUR returns recons_feats instead
+                recons = torch.stack([d["recons"] for d in per_step], dim=1)
+                recons = recons.reshape(B * num_preds, *recons.shape[2:])
+            recons_imgs = imgs.reshape(B * num_preds, C, H, W)
+            pred_imgs = imgs.clamp(0, 1)
     if rest is not None:                                              # join the decomposition of the later frames
         cur = torch.cuda.current_stream()
         cur.wait_stream(_encode_stream(videos.device))
         rest.record_stream(cur)
         slot_history = torch.cat([slot_history, rest], dim=1)
-    targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device).clamp(0, 1)
+    targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device)
+    if targets.is_cuda and targets.dtype == torch.float32 and (C * H * W) % 4 == 0 and targets.data_ptr() % 16 == 0:
+        from . import kernels as K
+        targets = K.clamp01_rows(targets)                 # one pass over the row-strided slice, torch.clamp semantics
+    else:
+        targets = targets.clamp(0, 1)
     # recons / recons_imgs: SAVi.decode's per-slot and composited frames, (B*P, ...) and UNclamped
     return {"slot_history": slot_history, "pred_slots": pred_slots, "pred_imgs": pred_imgs,
             "targets": targets, "masks": masks, "recons": recons, "recons_imgs": recons_imgs}
@@ -257,16 +304,6 @@ def forward_eval_decomp(decomp_model, videos, metric_tracker=None, **others):
     out = dict(out_model)
     out["recons_clamped"] = recons_imgs
     return out
-
-
-def psnr_per_frame(preds, targets, eps=1e-8):
-    """
-    (B, P, C, H, W) x2 -> (B, P) PSNR with piqa 1.2.2's definition 10*log10(1 / (mse + eps))
-    (lib/metrics.py:181-212).  Metric step AFTER the hot path: plain tensor
-    arithmetic, kept only so the multi-GPU gather has a real payload.
-    """
-    mse = ((preds - targets) ** 2).flatten(2).mean(dim=-1)
-    return 10.0 * torch.log10(1.0 / (mse + eps))
 
 
 def shard_batches(num_batches, rank, world_size):

@@ -65,6 +65,16 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_absmax_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_dec_tail_sum_placed_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
+    "tocvp_dec_tail_placed_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_clamp01_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
+                                              ctypes.c_long, ctypes.c_void_p]),
     "tocvp_gemm_wfrag_ws_bytes": (ctypes.c_size_t, []),
     "tocvp_gemm_f16wfrag_ws_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -427,6 +437,18 @@ def absmax(t):
     return struct.unpack("f", struct.pack("i", int(word.item())))[0]
 
 
+def clamp01_rows(src):
+    """ src (R, ...) fp32 whose rows are contiguous (any row stride) -> contiguous clamp(src, 0, 1) """
+    _dev_f32(src, "clamp01 operand")
+    R = src.shape[0]
+    assert R == 0 or src[0].is_contiguous()
+    out = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    row_len = out[0].numel() if R else 0
+    _check(lib().tocvp_clamp01_rows_f32(_ptr(src), src.stride(0) if R > 1 else row_len, _ptr(out), R, row_len, _stream()),
+           "tocvp_clamp01_rows_f32")
+    return out
+
+
 def _check_f16_range(amax, what, owner=None):
     """ checked pass (TOCVP_CHECK_RANGE=1 / check_range()): the fp16-plane arithmetic saturates at |x| = 255.9 """
     if not amax < F16X3_ACT_RANGE:                          # also trips on NaN
@@ -750,6 +772,8 @@ def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
     if ws is None:
         ws = slot_attn_workspace(B, N, q.device)
     assert ws.numel() * 4 >= lib().tocvp_slot_attn_ws_bytes(B, N)
+    if _CHECK_RANGE:            # q, k and v are split into fp16 planes of 2^8 x inside the kernel (saturating)
+        _check_f16_range(max(absmax(q), absmax(k), absmax(v)), "slot attention q / k / v")
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
     # units = algorithmic HBM bytes: k and v read once (B * 2 * N * D * sizeof)
     _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
@@ -881,26 +905,43 @@ def dec_tapsum(w):
     return out
 
 
-def dec_tail(x, w, bias, F, K, out=None):
+def _tail_outputs(F, K, H, W, dev, out):
     """
-    x: (F*K, H, W, Cin) NHWC -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W).
-    ``out`` = optional (imgs, recons, masks) contiguous views to write into.
+    (imgs, recons, masks, clamped or None) and their frame strides for the decoder tail kernels.  ``out`` = optional
+    (imgs, recons, masks[, clamped]) views to write into: each frame contiguous, frames any distance apart (e.g.
+    ``full.view(B, P, 3, H, W)[:, t]``: frame b of this call lands at row b * P + t of the full tensor).
     """
-    n, H, W, Cin = x.shape
-    assert n == F * K and x.is_contiguous()
-    dev = x.device
     if out is not None:
-        imgs, recons, masks = out
-        assert imgs.is_contiguous() and recons.is_contiguous() and masks.is_contiguous()
-        assert imgs.shape == (F, 3, H, W) and recons.shape == (F, K, 3, H, W)
+        imgs, recons, masks = out[:3]
+        clamped = out[3] if len(out) > 3 else None
+        assert imgs.shape == (F, 3, H, W) and recons.shape == (F, K, 3, H, W) and masks.shape == (F, K, 1, H, W)
+        for t_ in (imgs, recons, masks) + ((clamped,) if clamped is not None else ()):
+            _dev_f32(t_, "tail output")
+            assert t_[0].is_contiguous() if F else True, "every frame of a tail output must be contiguous"
+        if clamped is not None:
+            assert clamped.shape == imgs.shape and (F <= 1 or clamped.stride(0) == imgs.stride(0))
     else:
         imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
         recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
         masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
+        clamped = None
+    fs = [t_.stride(0) if F > 1 else t_[0].numel() if F else 0 for t_ in (imgs, recons, masks)]
+    return imgs, recons, masks, clamped, fs
+
+
+def dec_tail(x, w, bias, F, K, out=None):
+    """
+    x: (F*K, H, W, Cin) NHWC -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W).
+    ``out`` = optional (imgs, recons, masks[, clamped]) views to write into (see _tail_outputs).
+    """
+    n, H, W, Cin = x.shape
+    assert n == F * K and x.is_contiguous()
+    dev = x.device
+    imgs, recons, masks, clamped, fs = _tail_outputs(F, K, H, W, dev, out)
     ws = torch.empty(9 * Cin * 4, device=dev, dtype=torch.float32)
-    _check(lib().tocvp_dec_tail_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs),
-                                    _ptr(recons), _ptr(masks), F, K, H, W, Cin, _ptr(ws),
-                                    ws.numel() * 4, _stream()), "tocvp_dec_tail_f32")
+    _check(lib().tocvp_dec_tail_placed_f32(_ptr(x), _ptr(w.contiguous()), _ptr(bias), _ptr(imgs), _ptr(recons),
+                                           _ptr(masks), _ptr(clamped), fs[0], fs[1], fs[2], F, K, H, W, Cin,
+                                           _ptr(ws), ws.numel() * 4, _stream()), "tocvp_dec_tail_placed_f32")
     return imgs, recons, masks
 
 
@@ -942,19 +983,14 @@ def conv5x5_dec_f16x3_tail(x, wf, bias, taps, relu=True, out=None, pm_in=False, 
 
 
 def dec_tail_sum(products, bias, F, K, out=None):
-    """ tap products (F*K, 36, H, W) -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W) """
+    """ tap products (F*K, 36, H, W) -> recons_imgs (F,3,H,W), recons (F,K,3,H,W), masks (F,K,1,H,W); ``out`` as for
+    dec_tail """
     n, T, H, W = products.shape
     assert n == F * K and T == 36 and products.is_contiguous()
-    dev = products.device
-    if out is not None:
-        imgs, recons, masks = out
-        assert imgs.is_contiguous() and recons.is_contiguous() and masks.is_contiguous()
-    else:
-        imgs = torch.empty((F, 3, H, W), device=dev, dtype=torch.float32)
-        recons = torch.empty((F, K, 3, H, W), device=dev, dtype=torch.float32)
-        masks = torch.empty((F, K, 1, H, W), device=dev, dtype=torch.float32)
-    _check(lib().tocvp_dec_tail_sum_f32(_ptr(products), _ptr(bias), _ptr(imgs), _ptr(recons), _ptr(masks), F, K, H, W,
-                                        _stream()), "tocvp_dec_tail_sum_f32")
+    imgs, recons, masks, clamped, fs = _tail_outputs(F, K, H, W, products.device, out)
+    _check(lib().tocvp_dec_tail_sum_placed_f32(_ptr(products), _ptr(bias), _ptr(imgs), _ptr(recons), _ptr(masks),
+                                               _ptr(clamped), fs[0], fs[1], fs[2], F, K, H, W, _stream()),
+           "tocvp_dec_tail_sum_placed_f32")
     return imgs, recons, masks
 
 

@@ -64,7 +64,9 @@ class TextKV:
 def _ln(x, ln, add=None, split=0):
     # planes only for the many-row products: the skinny GEMMs of small batches take fp32 input (split-K over idle CUs,
     # 64-deep k-tiles), mid-size ones measured slower with planes -- and small-batch results stay what they were
-    if split and x.numel() // x.shape[-1] <= _PRESPLIT_MIN_ROWS:
+    # ... and never in a range-checked pass: a plane-producing epilogue saturates at |x| = 255.9 without a check of
+    # its own, so the checked pass hands fp32 tensors to the consuming GEMM, which verifies them (same arithmetic)
+    if split and (K._CHECK_RANGE or x.numel() // x.shape[-1] <= _PRESPLIT_MIN_ROWS):
         split = 0
     return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add, split=split)
 
@@ -76,7 +78,7 @@ def _ns(*dims, n_out=None):
     the activation (decides in the default "wide" policy).
     """
     ns = K.active_nsplit()
-    if _PRESPLIT == "0" or not ns:
+    if _PRESPLIT == "0" or not ns or K._CHECK_RANGE:     # checked pass: fp32 hand-over, verified by the consumer
         return 0
     if _PRESPLIT == "wide" and (ns != 22 or n_out is None or n_out < _PRESPLIT_MIN_N):
         return 0
@@ -87,7 +89,7 @@ def _mlp(x, seq, residual):
     """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
     ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0],
              n_out=seq[2].weight.shape[0])
-    if (_PRESPLIT_MLP and not ns and K.active_nsplit() == 22 and math.prod(tuple(x.shape[:-1])) > _PRESPLIT_MIN_ROWS
+    if (_PRESPLIT_MLP and not ns and not K._CHECK_RANGE and K.active_nsplit() == 22 and math.prod(tuple(x.shape[:-1])) > _PRESPLIT_MIN_ROWS
             and all(d % 64 == 0 for d in seq[0].weight.shape + seq[2].weight.shape[:1])):
         ns = 22                           # the hidden activation leaves the up-projection's epilogue as planes
     h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
@@ -149,7 +151,8 @@ class SlotAttention(nn.Module):
                               lambda: torch.cat([self.to_k.weight, self.to_v.weight], 0).contiguous())
         b = self._derived.get("b_kv", [self.to_k.bias, self.to_v.bias],
                               lambda: torch.cat([self.to_k.bias, self.to_v.bias], 0).contiguous())
-        planes = K.active_nsplit() == 22 and self.kv_planes and w.shape[0] == 2 * SD_PLANES
+        # (a range-checked pass keeps fp32 rows: slot_attn_iter verifies them before the kernel splits them itself)
+        planes = K.active_nsplit() == 22 and self.kv_planes and w.shape[0] == 2 * SD_PLANES and not K._CHECK_RANGE
         return K.linear(_ln(inputs, self.norm_input), w, b, out_split=22 if planes else 0)
 
     @staticmethod

@@ -121,14 +121,15 @@ class ConvDecoder(nn.Module):
     range_fallbacks = {"conv_precision": {"f16x3": "bf16x3", "f16f8": "bf16x3"}}
 
     # -- forward -------------------------------------------------------------------------------
-    def decode_slots(self, slots, pos_table):
+    def decode_slots(self, slots, pos_table, out=None):
         with K.range_owner(self, "conv_precision"):
-            return self._decode_slots(slots, pos_table)
+            return self._decode_slots(slots, pos_table, out=out)
 
-    def _decode_slots(self, slots, pos_table):
+    def _decode_slots(self, slots, pos_table, out=None):
         """
         slots (F, K, D), pos_table (H, W, D) -> recons_imgs (F,3,H,W), recons (F,K,3,H,W),
         masks (F,K,1,H,W)   (SAVi.decode, models/SAVi.py:241-261)
+        ``out`` = optional (recons_imgs, recons, masks[, clamped_imgs]) destination views (kernels._tail_outputs).
         """
         F_, Ks, D = slots.shape
         H, W, _ = pos_table.shape
@@ -136,9 +137,14 @@ class ConvDecoder(nn.Module):
         n_hidden = len(self.hidden_dims)
         cpos, tapsum = self._collapsed_layer0(pos_table)
         C0 = cpos.shape[-1]
-        imgs = torch.empty((F_, 3, H, W), device=dev, dtype=torch.float32)
-        recons = torch.empty((F_, Ks, 3, H, W), device=dev, dtype=torch.float32)
-        masks = torch.empty((F_, Ks, 1, H, W), device=dev, dtype=torch.float32)
+        if out is not None:
+            imgs, recons, masks = out[:3]
+            clamped = out[3] if len(out) > 3 else None
+        else:
+            imgs = torch.empty((F_, 3, H, W), device=dev, dtype=torch.float32)
+            recons = torch.empty((F_, Ks, 3, H, W), device=dev, dtype=torch.float32)
+            masks = torch.empty((F_, Ks, 1, H, W), device=dev, dtype=torch.float32)
+            clamped = None
         tail = self.decoder[n_hidden]
         fpc = max(1, self.max_slot_images // Ks)             # frames per chunk
         bufs = [None, None]
@@ -147,7 +153,7 @@ class ConvDecoder(nn.Module):
             f1 = min(F_, f0 + fpc)
             n = (f1 - f0) * Ks
             S = K.linear(slots[f0:f1].reshape(n, D), tapsum).reshape(n, 25, C0)
-            x, which, pm_prev, folded = None, 0, False, False
+            x, which, pm_prev, folded, check_last = None, 0, False, False, False
             for i in range(1, n_hidden):
                 conv = self.decoder[i].conv
                 co = conv.weight.shape[0]
@@ -159,6 +165,13 @@ class ConvDecoder(nn.Module):
                 split = self.conv_precision in ("bf16x3", "f16f8", "f16x3") and c64
                 fold = (self.tail_fold and i == n_hidden - 1 and i > 1 and self.conv_precision == "f16x3" and c64
                         and W % 64 == 0 and H % 8 == 0 and tuple(tail.weight.shape) == (4, 64, 3, 3))
+                if fold and K._CHECK_RANGE:
+                    # range-checked pass: the folded epilogue turns relu(y3) into fp16 operand planes (saturating at
+                    # 255.9) without ever materialising it, so THIS pass runs the layer unfolded below, verifies its
+                    # output against the plane range and hands it to the exact fp32 tail -- a checkpoint whose last
+                    # hidden activation leaves the range raises here and takes the decoder's fallback (bf16x3, no fold)
+                    fold = False
+                    check_last = True
                 if fold:
                     # last hidden layer: the tail's tap products leave its epilogue, the tail only sums them
                     if prod is None or prod.shape[0] != n:
@@ -191,11 +204,13 @@ class ConvDecoder(nn.Module):
                 else:
                     x = K.conv5x5(x, self._packed(i), conv.bias, relu=True, out=out)
                 which ^= 1
+            if check_last:
+                K._check_f16_range(K.absmax(x), "decoder: last hidden activation (operand of the folded tail)")
+            dst = (imgs[f0:f1], recons[f0:f1], masks[f0:f1]) + ((clamped[f0:f1],) if clamped is not None else ())
             if folded:
-                K.dec_tail_sum(prod, tail.bias, f1 - f0, Ks, out=(imgs[f0:f1], recons[f0:f1], masks[f0:f1]))
+                K.dec_tail_sum(prod, tail.bias, f1 - f0, Ks, out=dst)
             else:
-                K.dec_tail(x, tail.weight, tail.bias, f1 - f0, Ks,
-                           out=(imgs[f0:f1], recons[f0:f1], masks[f0:f1]))
+                K.dec_tail(x, tail.weight, tail.bias, f1 - f0, Ks, out=dst)
         return imgs, recons, masks
 
     def forward(self, x):

@@ -93,14 +93,33 @@ class CustomTokenizer:
         self.padding_idx = vocabulary["[PAD]"]
         self.vocabulary = vocabulary
         self.vocabulary_reverse = {v: k for k, v in vocabulary.items()}
+        self._split = self._resolve_backend()
 
-    @staticmethod
-    def _words(text):
+    _warned = False
+
+    @classmethod
+    def _resolve_backend(cls):
+        """
+        The word splitter, resolved ONCE: nltk.word_tokenize when nltk and its punkt data are usable (the
+        reference's splitter), else a regular expression -- with ONE warning, because the two differ on
+        contractions, hyphens, quotes and numbers (identical only on the CATER / CLIPort caption grammars).
+        Only the two "not installed" failures select the fallback; any other nltk error surfaces.
+        """
         try:
             import nltk
-            return nltk.word_tokenize(text)
-        except Exception:                                   # nltk (or its punkt data) absent
-            return re.findall(r"\w+|[^\w\s]", text)
+            nltk.word_tokenize("probe , sentence .")
+            return nltk.word_tokenize
+        except (ImportError, LookupError) as err:           # nltk absent / its punkt data absent
+            if not cls._warned:
+                import warnings
+                warnings.warn(f"CustomTokenizer: nltk.word_tokenize unavailable ({type(err).__name__}: {err}); "
+                              "splitting captions on word / punctuation boundaries instead -- identical on the CATER / "
+                              "CLIPort grammars, different on contractions, hyphens, quotes and numbers")
+                cls._warned = True
+            return lambda text: re.findall(r"\w+|[^\w\s]", text)
+
+    def _words(self, text):
+        return self._split(text)
 
     def text2tokens(self, x):
         return [self.vocabulary[w] for w in self._words(x)]

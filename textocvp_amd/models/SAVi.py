@@ -37,6 +37,7 @@ class SAVi(nn.Module, RangeGuard):
     """
 
     _replicate_for_data_parallel = refuse_replication      # one process per GPU, never DataParallel replicas
+    decode_accepts_out = True        # decode(slots, out=...) writes into caller-owned result views (evaluator)
 
     def __init__(self, num_slots, slot_dim, num_iterations=1, num_iterations_first=3,
                  in_channels=3, mlp_hidden=128, mlp_encoder_dim=128,
@@ -170,14 +171,17 @@ class SAVi(nn.Module, RangeGuard):
         require_inference(self)
         return self._encode_feats(x.contiguous())
 
-    def decode(self, slots):
+    def decode(self, slots, out=None):
         """
         slots (B', K, D) -> {'recons_imgs' (B',C,H,W), 'recons' (B',K,C,H,W), 'masks' (B',K,1,H,W)}
         (SAVi.py:241-261; softmax over slots at :254, compositing at :255)
+        ``out`` (extension) = (recons_imgs, recons, masks[, clamped_imgs]) views the tail kernel writes into -- every
+        frame contiguous, frames any distance apart -- so that per-step decodes land in the evaluator's (B * P, ...)
+        results without a stack / copy; ``clamped_imgs`` also receives clamp(recons_imgs, 0, 1).
         """
         require_inference(self)
         imgs, recons, masks = self.decoder.decode_slots(slots.contiguous(),
-                                                        self.decoder_pos_embedding.table())
+                                                        self.decoder_pos_embedding.table(), out=out)
         return {"recons_imgs": imgs, "recons": recons, "masks": masks}
 
     @torch.no_grad()
