@@ -115,6 +115,26 @@ int tocvp_gemm_f16planes_ws_f32(const void* A_planes, const void* W_planes, cons
 /* "f16x3": the same kernel with fp16 planes (x = hi + lo in fp16, 22 significant bits, products
  * hh + hl + lh): fp32-class accuracy at HALF the MFMA count of bf16x6, valid while |x| < 65504. */
 int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused predictor MLP (round 4, csrc/mlp_fused.hip):  Y = relu(X W1^T + b1) W2^T + b2 (+ R), the nn.Linear -> ReLU ->
+ * nn.Linear pairs of the reference's predictor blocks (models/Blocks/attention.py:355-359 applied at :395 / :521-523,
+ * and :428-432 applied at :461-463), in the f16x3 arithmetic of tocvp_gemm_bf16wfrag_f32 and bit-identical to that
+ * entry point called twice (c_split = 1 hidden planes in between): a workgroup owns 128 rows and walks the hidden
+ * dimension in chunks of 128, so the (M, Hd) hidden activation never reaches HBM.
+ *   x_planes: (M, 2, E) fp16 operand planes of 2^8 x (tocvp_layernorm_split_bf16 with split = 22, or any c_split
+ *   producer); w1_frag / w2_frag: tocvp_split_weights_frag_f16 of W1 (Hd, E) / W2 (E, Hd); b1 (Hd), b2 (E); R (M, E)
+ *   row stride ldr, or NULL; Y (M, E) row stride ldy.  E == 512, Hd % 128 == 0, M * E * 4 < 2^32.
+ *   Valid for |x|, |hidden| < 255, |w| < 63 (saturating beyond, like every fp16-plane kernel).
+ *   ws (nullable): tocvp_mlp_f16x3_fused_ws_bytes() bytes, zero on first use, one per stream.  With it the tiles of a
+ *   last, partly filled round of workgroups are cut into slices of the hidden dimension whose partial sums meet in the
+ *   workspace (added in slice order by the last arriver: deterministic; those rows then differ from the uncut sum in
+ *   the last bits, as any other summation order does).  Without it every tile is one workgroup.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_mlp_f16x3_fused_ws_bytes(void);
+int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_frag, const float* b1, const void* w2_frag,
+                              const float* b2, const float* R, int ldr, float* Y, int ldy, int M, int E, int Hd,
+                              void* ws, size_t ws_bytes, void* stream);
 int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
                             const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
                             int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);
