@@ -871,3 +871,49 @@ def test_conv5x5_f16x3_generic(Cin, Cout, n):
     err, err32 = (got.cpu().double() - ref).abs().max().item(), (got32.cpu().double() - ref).abs().max().item()
     print(f"conv5x5 f16x3 {Cin}->{Cout}: err {err:.2e} (fp32 mfma {err32:.2e})")
     assert err < max(3 * err32, 5e-6 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [32768, 38400, 12000, 11123])
+def test_mlp_fused_against_the_two_gemms(M, monkeypatch):
+    """
+    csrc/mlp_fused.hip: relu(x W1^T + b1) W2^T + b2 + residual in one launch (the predictor's nn.Linear -> ReLU ->
+    nn.Linear pairs, attention.py:355-359 / :428-432), hidden activation kept on the CU.  Rows of whole-tile
+    workgroups are BIT-IDENTICAL to the two f16x3 GEMMs with plane hand-over (same planes, same k order); the tiles of a
+    partly filled last round are cut along the hidden dimension and meet in the workspace: those rows agree to fp32
+    re-association (< 1e-5 here), every repetition is bit-identical, the arrival counters end at zero, and the whole
+    result is fp32-class against float64.  Rows that are not a multiple of 128 (11123) exercise the clamped tail tile.
+    """
+    k = _k()
+    E, Hd = 512, 2048
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, E, generator=g)
+    w1, b1 = (torch.rand(Hd, E, generator=g) - 0.5) * 2 * E ** -0.5, torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = (torch.rand(E, Hd, generator=g) - 0.5) * 2 * Hd ** -0.5, torch.randn(E, generator=g) * 0.1
+    res = torch.randn(M, E, generator=g)
+    xd, w1d, b1d, w2d, b2d, rd = (t.to(DEV) for t in (x, w1, b1, w2, b2, res))
+    gamma, beta = torch.ones(E, device=DEV), torch.zeros(E, device=DEV)
+    with k.gemm_precision("f16x3"):
+        xp = k.layer_norm(xd, gamma, beta, 1e-6, split=22)                 # the producer the predictor uses
+        assert isinstance(xp, k.SplitAct) and k.mlp_fused_ok(xp, w1d, w2d)
+        monkeypatch.setattr(k, "_MLP_FUSED", False)
+        assert not k.mlp_fused_ok(xp, w1d, w2d)
+        hid = k.linear(xp, w1d, b1d, act=k.ACT_RELU, out_split=22)
+        two = k.linear(hid, w2d, b2d, residual=rd)
+        del hid
+        monkeypatch.setattr(k, "_MLP_FUSED", True)
+        one = k.mlp_fused(xp, w1d, b1d, w2d, b2d, residual=rd)
+        for _ in range(5):
+            assert torch.equal(k.mlp_fused(xp, w1d, b1d, w2d, b2d, residual=rd), one)
+        no_res = k.mlp_fused(xp, w1d, b1d, w2d, b2d)
+    tiles, cus = (M + 127) // 128, torch.cuda.get_device_properties(0).multi_processor_count
+    whole = (tiles - tiles % cus) * 128 if tiles % cus and cus // (tiles % cus) >= 2 else M
+    assert torch.equal(one[:whole], two[:whole]), "whole-tile rows must equal the two-GEMM path bit for bit"
+    assert (one - two).abs().max().item() < 1e-5
+    close(no_res + rd, one, tol=1e-6)
+    xn = torch.nn.functional.layer_norm(x.double(), (E,), eps=1e-6)
+    ref = torch.relu(xn @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double() + res.double()
+    err, err2 = (one.cpu().double() - ref).abs().max().item(), (two.cpu().double() - ref).abs().max().item()
+    print(f"fused MLP {M} rows: {err:.2e} vs float64 (two GEMMs {err2:.2e}); whole-tile rows {whole}")
+    assert err < max(2.0 * err2, 5e-6)
+    wk = k._mlp_workspace(xd.device)[0]
+    assert int(wk[:1024].view(torch.int32).abs().sum()) == 0

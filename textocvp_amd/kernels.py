@@ -557,6 +557,58 @@ def _ksplit_workspace(device, stream=None):
     return rec
 
 
+# fused predictor MLP (csrc/mlp_fused.hip): relu(x W1^T + b1) W2^T + b2 + residual in ONE launch, the hidden activation
+# never reaches HBM.  Bit-identical to linear(linear(x, W1, b1, RELU, out_split=22), W2, b2, residual) on whole tiles;
+# the tiles of a partly filled last round of workgroups are cut along the hidden dimension through a per-stream workspace
+# (deterministic; those rows differ from the uncut sum in the last bits).  TOCVP_MLP_FUSED=0 keeps the two GEMMs.
+# Isolated, 38400 x 512 x 2048 x 512 (scripts/probes/mlp_fused_check.hip): 516 vs 636 us; below ~11000 rows a tile's
+# 8 MB weight stream (one workgroup per CU) no longer hides behind its products and the two GEMMs are faster.
+_MLP_FUSED = os.environ.get("TOCVP_MLP_FUSED", "1") != "0"
+_MLP_FUSED_MIN_ROWS = int(os.environ.get("TOCVP_MLP_FUSED_MIN_ROWS", "11000"))
+_MLP_WS = {}
+
+
+def _mlp_workspace(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    rec = _MLP_WS.get(key)
+    if rec is None:
+        nbytes = lib().tocvp_mlp_f16x3_fused_ws_bytes()
+        wk = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+        rec = _MLP_WS[key] = (wk, ctypes.c_void_p(wk.data_ptr()), nbytes)
+    return rec
+
+
+def mlp_fused_ok(x, w1, w2):
+    """ shapes / mode the fused MLP kernel takes: fp16-plane input of 512 features, hidden width a multiple of 128 """
+    return (_MLP_FUSED and not _CHECK_RANGE and isinstance(x, SplitAct) and x.nsplit == 22 and x.shape[-1] == 512
+            and tuple(w1.shape[1:]) == (512,) and w1.shape[0] % 128 == 0 and tuple(w2.shape) == (512, w1.shape[0])
+            and x.planes.shape[0] >= _MLP_FUSED_MIN_ROWS and x.planes.shape[0] * 2048 < 2 ** 32 and _WFRAG)
+
+
+def mlp_fused(x, w1, b1, w2, b2, residual=None):
+    """
+    x: SplitAct of fp16 planes (rows, 2, 512); w1 (Hd, 512), b1 (Hd), w2 (512, Hd), b2 (512) in nn.Linear layout;
+    residual (..., 512) fp32 or None -> relu(x w1^T + b1) w2^T + b2 + residual, shape x.shape.
+    """
+    assert mlp_fused_ok(x, w1, w2)
+    _dev_f32(w1, "w1"), _dev_f32(w2, "w2")
+    M, Hd = x.planes.shape[0], w1.shape[0]
+    w1c = w1 if w1.is_contiguous() else w1.contiguous()
+    w2c = w2 if w2.is_contiguous() else w2.contiguous()
+    f1, f2 = _split_weight(w1c, 22, frag=True), _split_weight(w2c, 22, frag=True)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, 512)
+        assert r2.shape[0] == M and r2.is_contiguous()
+    out = torch.empty((M, 512), device=w1.device, dtype=torch.float32)
+    _, wk_ptr, wk_bytes = _mlp_workspace(w1.device)
+    _timed(f"mlp_fused_{M}x512x{Hd}", 4.0 * M * 512 * Hd, lambda: _check(
+        lib().tocvp_mlp_f16x3_fused_f32(_ptr(x.planes), _ptr(f1), _ptr(b1), _ptr(f2), _ptr(b2), _ptr(r2), 512, _ptr(out),
+                                        512, M, 512, Hd, wk_ptr, wk_bytes, _stream()),
+        "tocvp_mlp_f16x3_fused_f32"))
+    return out.reshape(x.shape)
+
+
 # --------------------------------------------------------------------------------------------
 # tensor-level wrappers
 # --------------------------------------------------------------------------------------------

@@ -92,6 +92,10 @@ def _mlp(x, seq, residual):
     if (_PRESPLIT_MLP and not ns and not K._CHECK_RANGE and K.active_nsplit() == 22 and math.prod(tuple(x.shape[:-1])) > _PRESPLIT_MIN_ROWS
             and all(d % 64 == 0 for d in seq[0].weight.shape + seq[2].weight.shape[:1])):
         ns = 22                           # the hidden activation leaves the up-projection's epilogue as planes
+    if seq[0].bias is not None and seq[2].bias is not None and K.mlp_fused_ok(x, seq[0].weight, seq[2].weight):
+        # the predictor's 512 -> 2048 -> 512 pairs at many rows: ONE kernel, the hidden activation stays on the CU
+        # (csrc/mlp_fused.hip; bit-identical to the two GEMMs below on whole 128-row tiles)
+        return K.mlp_fused(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, residual=residual)
     h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
     return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
 
