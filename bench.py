@@ -123,6 +123,81 @@ def launch_workers(n, argv=None, device_count=None, popen=subprocess.Popen):
 
 
 # ------------------------------------------------------------------------------------------------
+# the timed region every rank runs (real worker and the CPU stub of tests/test_sharding_cpu.py alike)
+# ------------------------------------------------------------------------------------------------
+def run_timed(step, inp, warmup, steps, fence, gather, reduce_max, before=None, after=None):
+    """
+    W untimed warm-up steps, then EXACTLY K steps bracketed by ``fence()`` (barrier + device synchronise) on both sides;
+    the per-sequence metric rows of the K steps go through ``gather`` (the path's ONLY collective) inside the region;
+    the elapsed time is the MAX over ranks (``reduce_max``).  Returns (seconds, whatever ``after()`` returns, rows).
+    """
+    for _ in range(warmup):
+        step(inp)
+    fence()
+    if before is not None:
+        before()
+    metrics = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        metrics.append(step(inp))
+    import torch
+    gathered = gather(torch.cat(metrics, dim=0))
+    fence()
+    elapsed = time.perf_counter() - t0
+    extra = after() if after is not None else None
+    return reduce_max(elapsed), extra, gathered
+
+
+def stub_main(args):
+    """
+    CPU rehearsal of a worker (TOCVP_BENCH_STUB=1, gloo): the SAME launcher, environment, rendezvous, timed-region
+    protocol (run_timed), metric gather and rank-0 line as the real worker, with the hot path replaced by a
+    deterministic stand-in that encodes (rank, step-local sequence, frame) in its metric rows.  No GPU, no model:
+    it exists so that the first 8-GPU run cannot die in plumbing (tests/test_sharding_cpu.py).
+    """
+    import torch
+    import torch.distributed as dist
+    from textocvp_amd.evaluator import gather_metrics
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    B = args.batch
+
+    def step(_inp):
+        time.sleep(0.002 * (1 + rank % 3))                          # ranks finish at different times
+        seq = torch.arange(B, dtype=torch.float32).view(B, 1, 1)
+        frame = torch.arange(NUM_PREDS, dtype=torch.float32).view(1, NUM_PREDS, 1)
+        return (1000.0 * rank + 10.0 * seq + 0.01 * frame).expand(B, NUM_PREDS, 2).clone()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(elapsed):
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed, _, rows = run_timed(step, None, args.warmup, args.steps, fence, gather_metrics, reduce_max)
+    fail = os.environ.get("TOCVP_BENCH_STUB_FAIL_RANK")
+    if rank == 0:
+        frames = world * B * NUM_PREDS * args.steps
+        print(json.dumps({"metric": "predicted frames/sec (STUB: no model, launcher / rendezvous / gather rehearsal)",
+                          "value": round(frames / elapsed, 2), "unit": "predicted frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+                          "higher_is_better": True, "scaling": "weak", "stub": True,
+                          "gathered_rows": int(rows.shape[0]),
+                          "row_owner": [int(v) for v in (rows[:, 0, 0] // 1000).tolist()]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if fail is not None and int(fail) == rank:
+        sys.exit(7)                                                 # after the collectives: nobody hangs on this rank
+
+
+# ------------------------------------------------------------------------------------------------
 def host_cores():
     """ cores this process may really use: min(affinity mask, cgroup v2/v1 CPU quota) """
     cores = os.cpu_count() or 1
@@ -316,6 +391,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_workers(args.gpus))          # launcher: no GPU call before or after this line
+    if os.environ.get("TOCVP_BENCH_STUB", "0") != "0":
+        return stub_main(args)                        # CPU rehearsal of a worker (tests only)
 
     import torch
     import torch.distributed as dist
@@ -349,9 +426,9 @@ def main():
     synth.fill_module_(pred, prefix="pred.")
     savi, pred = savi.to(dev), pred.to(dev)
 
-    def make_inputs(B):
+    def make_inputs(B, caption_len=12):
         videos = synth.synth_videos(B, NUM_CONTEXT + NUM_PREDS, seed=100 + rank).to(dev)
-        tokens, lengths = synth.synth_captions(B, max_len=12, seed=100 + rank)
+        tokens, lengths = synth.synth_captions(B, max_len=caption_len, seed=100 + rank)
         return videos, tokens.to(dev), lengths.to(dev), synth.synth_noise(B, NUM_SLOTS, 128, seed=200 + rank).to(dev)
 
     def step(inp, **kw):
@@ -383,23 +460,21 @@ def main():
         videos, tokens, lengths, noise = inp
         return graphed(videos, caption_tokens=tokens, caption_lengths=lengths, init_noise=noise)["epilogue"].clone()
 
-    def timed(inp, warmup, steps, timer_only=("conv5x5",), step=step, **kw):
-        for _ in range(warmup):
-            step(inp, **kw)
-        fence()
-        kernels.TIMER = kernels.LaunchTimer(only=timer_only)
-        metrics = []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            metrics.append(step(inp, **kw))
-        gathered = gather_metrics(torch.cat(metrics, dim=0))      # the path's ONLY collective
-        fence()
-        elapsed = time.perf_counter() - t0
-        timer, kernels.TIMER = kernels.TIMER, None
+    def reduce_max(elapsed):
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), timer, gathered
+        return float(t.item())
+
+    def timed(inp, warmup, steps, timer_only=("conv5x5",), step=step, **kw):
+        def start_timer():
+            kernels.TIMER = kernels.LaunchTimer(only=timer_only)
+
+        def stop_timer():
+            timer, kernels.TIMER = kernels.TIMER, None
+            return timer
+        return run_timed(lambda i: step(i, **kw), inp, warmup, steps, fence, gather_metrics, reduce_max,
+                         before=start_timer, after=stop_timer)
 
     B = args.batch
     inp = make_inputs(B)
@@ -452,6 +527,18 @@ def main():
                                            "decoder overlapped with the rollout on a second stream; value is the "
                                            "faster of the two (mode)"}
         graphed._graphs.clear()
+        # the headline's caption has 12 tokens; the reference's text encoder admits 50 (text_encoders.py:36).  32-token
+        # captions still take the collapsed cross-attention (32 caption slots per head, csrc/xattn.hip)
+        inp_c = make_inputs(B, caption_len=32)
+        n = max(2, args.steps)
+        el_c, _, _ = timed(inp_c, 1, n)
+        extra["caption_32"] = {"value": round(world * B * NUM_PREDS * n / el_c, 2), "unit": "predicted frames/s",
+                               "batch_per_gpu": B, "ms_per_step": round(1e3 * el_c / n, 2), "caption_tokens": 32,
+                               "vs_headline": round((world * B * NUM_PREDS * n / el_c) / (world * B * NUM_PREDS * args.steps / elapsed), 4),
+                               "note": "configs[1] at the headline batch with 32-token captions (decoder overlapped, "
+                                       "eager): the cross-attention of 17-32 token captions is collapsed over the caption "
+                                       "like the 12-token one, with 32 caption slots per head"}
+        del inp_c
 
     if rank == 0 and world == 1 and extra is not None and not args.no_legs:
         log("extra legs: configs[3] (ExtendedDINOSAUR from pixels) and configs[4] (training step) ...")

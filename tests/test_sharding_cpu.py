@@ -120,3 +120,43 @@ def test_bench_launcher_argument_to_children_env():
     started.clear()
     assert bench.launch_workers(8, argv=[], device_count=1, popen=lambda cmd, env: FakeProc(cmd, env)) != 0
     assert started == []
+
+
+def _run_launcher(extra_env, *argv, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k_, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, cwd=root,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launcher_end_to_end_with_eight_stub_ranks():
+    """
+    ``python bench.py --gpus 8`` for real: the launcher starts eight fresh worker processes (nothing is mocked), they
+    rendezvous over gloo on 127.0.0.1, run the timed-region protocol of the real worker (bench.run_timed: warm-up,
+    barrier, K steps, the ONE gather of the metric rows, barrier, MAX of the elapsed time) on a CPU stand-in of the hot
+    path (TOCVP_BENCH_STUB=1) and rank 0 prints the line.  Checks: n_gpus, every rank's rows present and in rank order,
+    a failing rank's exit code reaches the launcher's, and the launcher refuses (starting nothing) when fewer devices
+    than ranks are visible and the backend is RCCL.
+    """
+    import json
+    stub = {"TOCVP_BENCH_STUB": "1", "TOCVP_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}
+    res = _run_launcher(stub, "--gpus", "8", "--batch", "2", "--steps", "2", "--warmup", "1")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                              # rank 0 alone prints
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["gathered_rows"] == 8 * 2 * 2                       # ranks x steps x sequences per step
+    assert line["row_owner"] == [r for r in range(8) for _ in range(4)]     # rows in rank order
+    assert line["value"] > 0 and line["ms_per_step"] >= 2.0         # the slowest rank (6 ms per step) sets the time
+    # a rank that fails AFTER the collectives: every other rank ends cleanly, the launcher returns the worst code
+    res = _run_launcher(dict(stub, TOCVP_BENCH_STUB_FAIL_RANK="5"), "--gpus", "8", "--batch", "1", "--steps", "1",
+                        "--warmup", "0")
+    assert res.returncode == 7, (res.returncode, res.stderr[-1000:])
+    # RCCL backend with fewer visible devices than ranks (this container has none): refuse, start nothing
+    res = _run_launcher({"TOCVP_BENCH_STUB": "1"}, "--gpus", "8", "--batch", "1", "--steps", "1")
+    assert res.returncode == 2 and "GPU(s) are visible" in res.stderr and not res.stdout.strip()

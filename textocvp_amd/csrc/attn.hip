@@ -62,15 +62,19 @@ __device__ __forceinline__ void store_qk(float* row, int c, f32x4 v, int DH, boo
     *reinterpret_cast<h16x4*>(b + DH * 2 + c * 2) = lo;
 }
 
-template <int DH, bool QK16>
-__global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
+// NW = waves per workgroup = 32-query blocks per workgroup: 4 (128 queries) or 2 (64 queries, round 4).  At 300 tokens
+// three 128-query workgroups hold 128 + 128 + 44 queries -- the third runs as long as the others with two of its four
+// waves idle (22 % of the query slots) -- five 64-query workgroups hold 320 slots.
+template <int DH, bool QK16, int NW>
+__global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
+    constexpr int QB = 32 * NW, NT = 64 * NW;    // queries / threads per workgroup
     constexpr int QS = DH + 4;          // padded row stride of Q / K tiles (floats; = 2 fp16 planes + pad)
     constexpr int F4 = DH / 4;          // float4 per row
     constexpr int ND = DH / 32;         // 32-wide blocks of the head dim
     constexpr int VTB = 144;            // QK16: bytes per row of the transposed V image [dh][32 keys hi | lo | pad]
-    __shared__ __attribute__((aligned(16))) float lds[128 * QS + 32 * QS + (QK16 ? DH * (VTB / 4) : 32 * DH)];
+    __shared__ __attribute__((aligned(16))) float lds[QB * QS + 32 * QS + (QK16 ? DH * (VTB / 4) : 32 * DH)];
     float* Qs = lds;
-    float* Ks = lds + 128 * QS;
+    float* Ks = lds + QB * QS;
     float* Vs = Ks + 32 * QS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
     // Linear workgroup ids are dealt round-robin over the 8 XCDs (private L2 each): the query blocks of one
     // (batch, head) get ids with the same value mod 8, so the keys / values they all stream are fetched into ONE L2
     // (three 128-query blocks at 300 tokens read the same 154 KB; dealt in launch order they hit three XCDs).
-    const int gx = (p.Tq + 127) / 128;
+    const int gx = (p.Tq + QB - 1) / QB;
     const int bh = p.xcd ? (blockIdx.x / (8 * gx)) * 8 + (blockIdx.x & 7) : blockIdx.x / gx;
     if (bh >= p.B * p.H) return;
     const int b = bh / p.H, head = bh % p.H;
-    const int q0 = (p.xcd ? (blockIdx.x >> 3) % gx : blockIdx.x % gx) * 128;
+    const int q0 = (p.xcd ? (blockIdx.x >> 3) % gx : blockIdx.x % gx) * QB;
 
     const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + head * DH;
     const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         kv_len = kv_len < 1 ? 1 : (kv_len > p.Tk ? p.Tk : kv_len);
     }
 
-    // ---- stage the 128 query rows (zeros past Tq)
-    for (int i = t; i < 128 * F4; i += 256) {
+    // ---- stage the query rows (zeros past Tq)
+    for (int i = t; i < QB * F4; i += NT) {
         const int r = i / F4, c = (i % F4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (q0 + r < p.Tq) v = *reinterpret_cast<const f32x4*>(Qb + (size_t)(q0 + r) * p.ldq + c);
@@ -114,12 +118,12 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
     const int nkb = (kv_len + 31) / 32;
     // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
     // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
-    constexpr int NITM = (32 * F4 + 255) / 256;                    // items per thread: DH 64 -> 2, DH 32 -> 1
+    constexpr int NITM = (32 * F4 + NT - 1) / NT;                  // items per thread (4 waves): DH 64 -> 2, DH 32 -> 1
     f32x4 kreg[NITM], vreg[NITM];
     auto kv_load = [&](int kb) {
 #pragma unroll
         for (int it = 0; it < NITM; ++it) {
-            const int i = min(t + 256 * it, 32 * F4 - 1);
+            const int i = min(t + NT * it, 32 * F4 - 1);
             const int r = i / F4, c = (i % F4) * 4;
             const int key = min(kb * 32 + r, p.Tk - 1);
             kreg[it] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(MhaArgs p) {
         __syncthreads();   // previous tile fully consumed (also orders the Q staging)
 #pragma unroll
         for (int it = 0; it < NITM; ++it) {
-            const int i = t + 256 * it;
+            const int i = t + NT * it;
             if (i >= 32 * F4) continue;
             const int r = i / F4, c = (i % F4) * 4;
             const bool valid = kb * 32 + r < p.Tk;
@@ -302,15 +306,26 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
     if (B == 0) return TOCVP_OK;
     static const int xcd = []() { const char* e = getenv("TOCVP_MHA_XCD"); return e ? atoi(e) : 1; }();
     MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd};
-    dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + 127) / 128)));
+    // 64-query workgroups where they leave fewer empty query slots than 128-query ones (300 tokens: 320 against 384);
+    // TOCVP_MHA_NW=4 / 2 pins one form
+    static const int nw_env = []() { const char* e = getenv("TOCVP_MHA_NW"); return e ? atoi(e) : 0; }();
+    const int nw = nw_env == 2 || nw_env == 4 ? nw_env : ((Tq + 63) / 64 * 64 < (Tq + 127) / 128 * 128 ? 2 : 4);
+    const int qb = 32 * nw;
+    dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + qb - 1) / qb)));
     hipStream_t s = static_cast<hipStream_t>(stream);
+#define TOCVP_MHA_GO(DH_, QK_)                                                                              \
+    do {                                                                                                    \
+        if (nw == 2) hipLaunchKernelGGL((mha_f32_kernel<DH_, QK_, 2>), grid, dim3(128), 0, s, p);           \
+        else hipLaunchKernelGGL((mha_f32_kernel<DH_, QK_, 4>), grid, dim3(256), 0, s, p);                   \
+    } while (0)
     if (dh == 64) {
-        if (qk16) hipLaunchKernelGGL((mha_f32_kernel<64, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((mha_f32_kernel<64, false>), grid, dim3(256), 0, s, p);
+        if (qk16) TOCVP_MHA_GO(64, true);
+        else TOCVP_MHA_GO(64, false);
     } else {
-        if (qk16) hipLaunchKernelGGL((mha_f32_kernel<32, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((mha_f32_kernel<32, false>), grid, dim3(256), 0, s, p);
+        if (qk16) TOCVP_MHA_GO(32, true);
+        else TOCVP_MHA_GO(32, false);
     }
+#undef TOCVP_MHA_GO
     return tocvp_launch_status();
 }
 

@@ -30,13 +30,17 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int E = 512, HEADS = 8, LP = 16, NP = HEADS * LP;          // 128 padded score columns
+constexpr int E = 512, HEADS = 8;
+constexpr int LP = 16, NP = HEADS * LP;                              // 128 padded score columns (captions of <= 16 tokens)
 constexpr int TOK = 64;                                              // tokens per workgroup
 constexpr int KC = 128;                                              // LayerNorm image: columns per chunk
 constexpr int XROW = 2 * KC * 2 + 16;                                // [row][plane][KC] + 16 B pad = 528 B
 constexpr int PROW = 2 * NP * 2 + 16;                                // P image: [row][plane][n] + 16 B pad = 528 B
 constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
 static_assert(XROW == PROW, "the P image overlays the LayerNorm image");
+// Round 4: captions of 17-32 tokens take LPT = 32 caption slots per head (one 32-row score tile per head, 256 padded
+// score columns: still half the 512 x 512 projections' work); the text encoder admits 50 tokens
+// (text_encoders.py:36) -- 33-50 would need 64 slots per head = the uncollapsed width, they keep the four-kernel path.
 
 struct XArgs {
     const float* x; const float* gamma; const float* beta; float eps;
@@ -50,8 +54,12 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
 
 // 8 waves, 64 tokens of one sample.  34 KB of LDS and ~100 registers: four workgroups (32 waves) per CU -- the kernel
 // is a chain of short dependent phases, what hides their latency is other workgroups.
-__global__ __launch_bounds__(512, 6) void xattn_collapsed_kernel(XArgs p, int gx) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TOK * XROW];
+template <int LPT>
+__global__ __launch_bounds__(512, LPT == 16 ? 6 : 4) void xattn_collapsed_kernel(XArgs p, int gx) {
+    constexpr int NPT = HEADS * LPT;                                 // padded score columns
+    constexpr int PROWT = 2 * NPT * 2 + 16;                          // P image row: [plane][n] + 16 B pad
+    constexpr int NMB = LPT == 16 ? 1 : 2;                           // token blocks per wave in phase 1
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TOK * (PROWT > XROW ? PROWT : XROW)];
     __shared__ float stats[TOK * 2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -92,13 +100,16 @@ __global__ __launch_bounds__(512, 6) void xattn_collapsed_kernel(XArgs p, int gx
     __syncthreads();
 
     // ---- phase 1: S^T = G LN(x)^T, LN(x) staged in chunks of 128 columns as fp16 operand planes.
-    // wave -> score rows n = 32 (wave & 3) + .. (heads 2 (wave & 3), + 1), tokens m = 32 (wave >> 2) + ..
-    const int nb = wave & 3, mb = wave >> 2;
-    f32x16 sacc;
+    // LPT = 16: wave -> score rows n = 32 (wave & 3) + .. (heads 2 (wave & 3), + 1), tokens m = 32 (wave >> 2) + ..
+    // LPT = 32: wave -> the 32 caption slots of head `wave`, both token blocks (one G fragment feeds two products)
+    const int nb = LPT == 16 ? (wave & 3) : wave, mb0 = LPT == 16 ? (wave >> 2) : 0;
+    f32x16 sacc[NMB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NP / 32) + nb) * (E / 16) * 2) * 64 + lane;
-    const unsigned char* xl = lds + (32 * mb + l31) * XROW + hh * 16;
+    for (int i = 0; i < NMB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+    const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NPT / 32) + nb) * (E / 16) * 2) * 64 + lane;
+    const unsigned char* xl = lds + (32 * mb0 + l31) * XROW + hh * 16;
 #pragma unroll 1
     for (int ch = 0; ch < E / KC; ++ch) {
         if (ch > 0) __syncthreads();                  // every wave has finished reading the previous chunk
@@ -124,65 +135,72 @@ __global__ __launch_bounds__(512, 6) void xattn_collapsed_kernel(XArgs p, int gx
         __syncthreads();
 #pragma unroll 2
         for (int ks = 0; ks < KC / 16; ++ks) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + ks * 32);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(xl + KC * 2 + ks * 32);
             const f16x8 wh = gf[(size_t)(ch * (KC / 16) + ks) * 128];
             const f16x8 wl = gf[(size_t)(ch * (KC / 16) + ks) * 128 + 64];
-            sacc = mfma16(wh, al, sacc);
-            sacc = mfma16(wl, ah, sacc);
-            sacc = mfma16(wh, ah, sacc);
+#pragma unroll
+            for (int i = 0; i < NMB; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + i * 32 * XROW + ks * 32);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(xl + i * 32 * XROW + KC * 2 + ks * 32);
+                sacc[i] = mfma16(wh, al, sacc[i]);
+                sacc[i] = mfma16(wl, ah, sacc[i]);
+                sacc[i] = mfma16(wh, ah, sacc[i]);
+            }
         }
     }
-    // softmax over the caption slots of each head: register r of lane half hh = slot t = 4 hh + (r & 3) + 8 ((r >> 2) & 1)
-    // of head 2 nb + (r >> 3); the other half of the slots sits in lane ^ 32
-    float pr[16];
+    // softmax over the caption slots of each head.  Register r of lane half hh = score row (r & 3) + 8 (r >> 2) + 4 hh
+    // of the tile; the other half of the rows sits in lane ^ 32.  LPT = 16: rows 0-15 / 16-31 = heads 2 nb / 2 nb + 1
+    // (registers 0-7 / 8-15); LPT = 32: the tile is one head
+    float pr[NMB][16];
+    constexpr int NG = 32 / LPT, RG = 16 / NG;        // heads per tile, registers per head and lane
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float mx = -3.0e38f;
+    for (int i = 0; i < NMB; ++i)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
-            const float sv = sacc[8 * g + q] * p.scale;
-            pr[8 * g + q] = sv;
-            if (tt < p.Lt) mx = fmaxf(mx, sv);
+        for (int g = 0; g < NG; ++g) {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+                const float sv = sacc[i][RG * g + q] * p.scale;
+                pr[i][RG * g + q] = sv;
+                if (tt < p.Lt) mx = fmaxf(mx, sv);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
+                const float e = tt < p.Lt ? expf(pr[i][RG * g + q] - mx) : 0.f;
+                pr[i][RG * g + q] = e;
+                sum += e;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int q = 0; q < RG; ++q) pr[i][RG * g + q] *= inv;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
-            const float e = tt < p.Lt ? expf(pr[8 * g + q] - mx) : 0.f;
-            pr[8 * g + q] = e;
-            sum += e;
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pr[8 * g + q] *= inv;
-    }
     __syncthreads();                                  // every wave has finished reading the LN image
-    // P as operand planes: row m = 32 mb + l31, column n = 32 nb + 16 g + 8 u + 4 hh + {0..3}
+    // P as operand planes: row m = 32 (mb0 + i) + l31, column n = 32 nb + 8 u + 4 hh + {0..3} for register quad u
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < NMB; ++i)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             f16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float sc = pr[8 * g + 4 * u + e] * SA;
+                const float sc = pr[i][4 * u + e] * SA;
                 hi[e] = (_Float16)sc;
                 lo[e] = (_Float16)(sc - (float)hi[e]);
             }
-            const int n = 32 * nb + 16 * g + 8 * u + 4 * hh;
-            *reinterpret_cast<f16x4*>(lds + (32 * mb + l31) * PROW + n * 2) = hi;
-            *reinterpret_cast<f16x4*>(lds + (32 * mb + l31) * PROW + NP * 2 + n * 2) = lo;
+            const int n = 32 * nb + 8 * u + 4 * hh;
+            *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + n * 2) = hi;
+            *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + NPT * 2 + n * 2) = lo;
         }
     __syncthreads();
 
     // ---- phase 2: Y^T tiles of this wave, one 32-column block at a time (keeps the kernel at 3 workgroups per CU):
     // rows c = 64 wave + 32 j + .., columns m = 32 i + ..; register quad q of tile (j, i) = columns
     // 64 wave + 32 j + 8 q + 4 hh .. + 3 of token r0 + 32 i + l31
-    const unsigned char* pl = lds + l31 * PROW + hh * 16;
+    const unsigned char* pl = lds + l31 * PROWT + hh * 16;
 #pragma unroll 1
     for (int j = 0; j < 2; ++j) {
         f32x16 yacc[2];
@@ -191,14 +209,14 @@ __global__ __launch_bounds__(512, 6) void xattn_collapsed_kernel(XArgs p, int gx
 #pragma unroll
             for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
         const f16x8* hf = reinterpret_cast<const f16x8*>(p.Hf) +
-                          ((size_t)(b * (E / 32) + wave * 2 + j) * (NP / 16) * 2) * 64 + lane;
+                          ((size_t)(b * (E / 32) + wave * 2 + j) * (NPT / 16) * 2) * 64 + lane;
 #pragma unroll 2
-        for (int ks = 0; ks < NP / 16; ++ks) {
+        for (int ks = 0; ks < NPT / 16; ++ks) {
             const f16x8 wh = hf[ks * 128], wl = hf[ks * 128 + 64];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROW + ks * 32);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROW + NP * 2 + ks * 32);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROWT + ks * 32);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(pl + i * 32 * PROWT + NPT * 2 + ks * 32);
                 yacc[i] = mfma16(wh, al, yacc[i]);
                 yacc[i] = mfma16(wl, ah, yacc[i]);
                 yacc[i] = mfma16(wh, ah, yacc[i]);
@@ -421,7 +439,7 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
                                          const void* Gfrag, const void* Hfrag, const float* bias, float* y, int B,
                                          int Tq, int E_, int heads, int Lt, float scale, void* stream) {
     TOCVP_CHECK_ARG(x && gamma && beta && Gfrag && Hfrag && bias && y);
-    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= LP);
+    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= 2 * LP);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) || !tocvp_aligned16(beta) ||
         !tocvp_aligned16(bias) || !tocvp_aligned16(Gfrag) || !tocvp_aligned16(Hfrag))
         return TOCVP_EALIGN;
@@ -434,12 +452,17 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n;
     }();
+    if (Lt > LP) {            // 17-32 caption tokens: 32 slots per head (operands built with that padding)
+        hipLaunchKernelGGL(xattn_collapsed_kernel<32>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p, gx);
+        return tocvp_launch_status();
+    }
     if ((long)B * gx < ncu && B <= 65535) {
         hipLaunchKernelGGL(xattn_collapsed_small_kernel, dim3((Tq + 31) / 32, B), dim3(256), 0,
                            static_cast<hipStream_t>(stream), p);
         return tocvp_launch_status();
     }
-    hipLaunchKernelGGL(xattn_collapsed_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
+    hipLaunchKernelGGL(xattn_collapsed_kernel<16>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
                        static_cast<hipStream_t>(stream), p, gx);
     return tocvp_launch_status();
 }

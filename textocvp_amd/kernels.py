@@ -729,6 +729,22 @@ def layer_norm(x, gamma, beta, eps, add=None, split=0):
     return y.reshape(x.shape)
 
 
+def bmm_f32(A, B, C, M, N, Kd, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0), sB=(0, 0),
+            sC=(0, 0), alpha=1.0, accumulate=False):
+    """
+    C[b1, b2] (M x N) = alpha * op(A[b1, b2]) (M x Kd) * op(B[b1, b2]) (Kd x N) on the exact fp32 MFMA (tocvp_bmm_f32):
+    A, B, C are device fp32 tensors whose data_ptr() is element (0, 0) of slice (0, 0); ld* leading dimensions and
+    s* = (stride of b1, stride of b2) in elements address the slices in place.
+    """
+    for t_ in (A, B, C):
+        _dev_f32(t_, "bmm operand")
+    _check(lib().tocvp_bmm_f32(_ptr(A), int(lda), int(sA[0]), int(sA[1]), int(bool(transA)), _ptr(B), int(ldb),
+                               int(sB[0]), int(sB[1]), int(bool(transB)), _ptr(C), int(ldc), int(sC[0]), int(sC[1]),
+                               int(batch[0]), int(batch[1]), int(M), int(N), int(Kd), float(alpha),
+                               int(bool(accumulate)), _stream()), "tocvp_bmm_f32")
+    return C
+
+
 def xattn_operands(G, HT):
     """
     G (B * 128, 512), HT (B * 512, 128) fp32 -> their fp16 operand planes (2^10 w = hi + lo) in MFMA-fragment
@@ -754,12 +770,13 @@ def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
     """
     _dev_f32(x, "x")
     B, Tq, E = x.shape
-    assert x.is_contiguous() and Gf.shape[0] == B * heads * 16 and Hf.shape[0] == B * E
+    LP = 16 if Lt <= 16 else 32                    # caption slots per head the operands were padded to
+    assert x.is_contiguous() and Gf.shape[0] == B * heads * LP and Hf.shape[0] == B * E and Lt <= 32
     if _CHECK_RANGE:                               # |LayerNorm(x)| <= sqrt(E) max|gamma| + max|beta|
         _check_f16_range(absmax(gamma) * E ** 0.5 + absmax(beta),
                          "collapsed cross-attention: bound of the LayerNorm output")
     y = torch.empty_like(x)
-    _timed(f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * 16, lambda: _check(
+    _timed(f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * LP, lambda: _check(
         lib().tocvp_xattn_collapsed_f32(_ptr(x), _ptr(gamma), _ptr(beta), float(eps), _ptr(Gf), _ptr(Hf), _ptr(bias),
                                         _ptr(y), B, Tq, E, int(heads), int(Lt), float(scale), _stream()),
         "tocvp_xattn_collapsed_f32"))

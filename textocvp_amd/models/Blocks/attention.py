@@ -53,7 +53,7 @@ _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
 
 class TextKV:
     """ step-invariant caption operands of one predictor block: the fused [k | v] projection (B, Lt, 2 inner) and,
-    for captions of at most 16 tokens, the collapsed operands (G fragments, HT fragments, Lt) of csrc/xattn.hip """
+    for captions of at most 32 tokens, the collapsed operands (G fragments, HT fragments, Lt) of csrc/xattn.hip """
 
     __slots__ = ("kv", "collapsed")
 
@@ -307,32 +307,34 @@ class MultiHeadCrossAttention(MetaAttention):
         Fold the query and output projections into per-sample operands of the caption (csrc/xattn.hip):
             G[b, h, t, :]  = sum_d Wq[h dh + d, :] K[b, t, h dh + d]      scores = LN(x) G^T (x dim_head ** -0.5)
             HT[b, :, h, t] = sum_d Wo[:, h dh + d] V[b, t, h dh + d]      output = P HT^T
-        as fp16 operand planes in MFMA-fragment order, caption slots of a head padded to 16.  Built once per
+        as fp16 operand planes in MFMA-fragment order, caption slots of a head padded to 16 or 32.  Built once per
         caption batch; exact up to fp32 re-association.  None when the shapes do not fit the fused kernel
-        (more than 16 caption tokens, other widths) -- the caller then takes the four-kernel path.
+        (more than 32 caption tokens, other widths) -- the caller then takes the four-kernel path.
         """
         B, Lt, two_inner = kv.shape
         H, dh, inner = self.num_heads, self.dim_head, two_inner // 2
         E_in, E_out = self.q.weight.shape[1], self.out_projection.weight.shape[0]
-        if not (_XATTN_COLLAPSE and Lt <= 16 and H == 8 and dh == 64 and E_in == 512 and E_out == 512 and
-                self.out_projection.bias is not None and K.active_nsplit() == 22):
+        if not (_XATTN_COLLAPSE and Lt <= 32 and H == 8 and dh == 64 and E_in == 512 and E_out == 512 and
+                self.out_projection.bias is not None and K.active_nsplit() == 22 and kv.is_contiguous()
+                and B * H <= 65535):
             return None
-        wq_t = self._derived.get("wq_heads", [self.q.weight], lambda: [
-            self.q.weight[h * dh:(h + 1) * dh, :].t().contiguous() for h in range(H)])          # (E_in, dh) each
-        wo_h = self._derived.get("wo_heads", [self.out_projection.weight], lambda: [
-            self.out_projection.weight[:, h * dh:(h + 1) * dh].contiguous() for h in range(H)])  # (E_out, dh) each
-        # per head one small GEMM each into contiguous slabs, then ONE strided copy per operand into the padded layout
-        g_heads = torch.empty((H, B * Lt, E_in), device=kv.device, dtype=torch.float32)
-        h_heads = torch.empty((H, B * Lt, E_out), device=kv.device, dtype=torch.float32)
-        kv_h = kv.view(B, Lt, 2, H, dh).permute(2, 3, 0, 1, 4).contiguous().view(2, H, B * Lt, dh)   # one copy
-        for h in range(H):
-            K.linear(kv_h[0, h], wq_t[h], out=g_heads[h])
-            K.linear(kv_h[1, h], wo_h[h], out=h_heads[h])
-        G = torch.zeros((B, H, 16, E_in), device=kv.device, dtype=torch.float32)
-        HT = torch.zeros((B, E_out, H, 16), device=kv.device, dtype=torch.float32)
-        G[:, :, :Lt] = g_heads.view(H, B, Lt, E_in).permute(1, 0, 2, 3)
-        HT[:, :, :, :Lt] = h_heads.view(H, B, Lt, E_out).permute(1, 3, 0, 2)
-        return K.xattn_operands(G.view(B * H * 16, E_in), HT.view(B * E_out, H * 16)) + (Lt,)
+        # caption slots of a head padded to 16 (captions of at most 16 tokens) or 32 (17-32): with 32 the fused kernel
+        # still does half the work of the 512 x 512 projections; 33-50 tokens (text_encoders.py:36 admits 50) would need 64
+        # slots per head = the uncollapsed width and keep the four-kernel path
+        LP = 16 if Lt <= 16 else 32
+        # both operands from ONE batched launch each over (sample, head), slices addressed in place (round 3: 16 small
+        # GEMMs + two strided copies, 351 us per block): exact fp32 MFMA, rows / columns behind Lt stay zero
+        G = torch.zeros((B, H, LP, E_in), device=kv.device, dtype=torch.float32)
+        HT = torch.zeros((B, E_out, H, LP), device=kv.device, dtype=torch.float32)
+        wq, wo = self.q.weight, self.out_projection.weight
+        assert wq.is_contiguous() and wo.is_contiguous()
+        # G[b, h] (Lt x E_in) = K[b, :, h dh : (h + 1) dh] (Lt x dh) @ Wq[h dh : (h + 1) dh, :] (dh x E_in)
+        K.bmm_f32(kv, wq, G, Lt, E_in, dh, lda=two_inner, ldb=E_in, ldc=E_in, batch=(B, H),
+                  sA=(Lt * two_inner, dh), sB=(0, dh * E_in), sC=(H * LP * E_in, LP * E_in))
+        # HT[b, :, h, :Lt] (E_out x Lt) = Wo[:, h dh : (h + 1) dh] (E_out x dh) @ V[b, :, h dh : (h + 1) dh]^T (dh x Lt)
+        K.bmm_f32(wo, kv[:, :, inner:], HT, E_out, Lt, dh, lda=inner, ldb=two_inner, ldc=H * LP, transB=True,
+                  batch=(B, H), sA=(0, dh), sB=(Lt * two_inner, dh), sC=(E_out * H * LP, LP))
+        return K.xattn_operands(G.view(B * H * LP, E_in), HT.view(B * E_out, H * LP)) + (Lt,)
 
     def forward(self, enc_embs, query_embs, residual=None, kv=None, **kwargs):
         if kv is None:
