@@ -62,9 +62,10 @@ __device__ __forceinline__ void store_qk(float* row, int c, f32x4 v, int DH, boo
     *reinterpret_cast<h16x4*>(b + DH * 2 + c * 2) = lo;
 }
 
-// NW = waves per workgroup = 32-query blocks per workgroup: 4 (128 queries) or 2 (64 queries, round 4).  At 300 tokens
-// three 128-query workgroups hold 128 + 128 + 44 queries -- the third runs as long as the others with two of its four
-// waves idle (22 % of the query slots) -- five 64-query workgroups hold 320 slots.
+// NW = waves per workgroup = 32-query blocks per workgroup: 4 (128 queries, default) or 2 (64 queries, round 4,
+// opt-in).  At 300 tokens three 128-query workgroups hold 128 + 128 + 44 queries -- the third runs as long as the others
+// with two of its four waves idle (22 % of the query slots) -- five 64-query workgroups hold 320 slots, yet measure
+// slower (see mha_launch).
 template <int DH, bool QK16, int NW>
 __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     constexpr int QB = 32 * NW, NT = 64 * NW;    // queries / threads per workgroup
@@ -306,10 +307,12 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
     if (B == 0) return TOCVP_OK;
     static const int xcd = []() { const char* e = getenv("TOCVP_MHA_XCD"); return e ? atoi(e) : 1; }();
     MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd};
-    // 64-query workgroups where they leave fewer empty query slots than 128-query ones (300 tokens: 320 against 384);
-    // TOCVP_MHA_NW=4 / 2 pins one form
+    // 64-query workgroups (TOCVP_MHA_NW=2) leave fewer empty query slots (300 tokens: 320 against 384) but measured
+    // SLOWER in the rollout, 245 against 194 us at 128 x 8 x 300 x 300 (two A/B rounds on one box): 176 registers
+    // -> two waves per SIMD instead of three, and every workgroup stages (splits, transposes) the same K / V tiles for
+    // half as many queries.  128-query workgroups stay the default.
     static const int nw_env = []() { const char* e = getenv("TOCVP_MHA_NW"); return e ? atoi(e) : 0; }();
-    const int nw = nw_env == 2 || nw_env == 4 ? nw_env : ((Tq + 63) / 64 * 64 < (Tq + 127) / 128 * 128 ? 2 : 4);
+    const int nw = nw_env == 2 ? 2 : 4;
     const int qb = 32 * nw;
     dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + qb - 1) / qb)));
     hipStream_t s = static_cast<hipStream_t>(stream);

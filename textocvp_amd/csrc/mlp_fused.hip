@@ -43,6 +43,7 @@ constexpr int XROW = 256;                    // bytes per token in an X stage: [
 constexpr int XSTAGE = BM * XROW;            // 32 KB
 constexpr int HROW = 512;                    // bytes per token in the h image: [plane 0: 128 hidden | plane 1]
 constexpr int HBYTES = BM * HROW;            // 64 KB
+constexpr int NXS = 3;                       // X stages: the LDS-DMA runs two k-tiles ahead of the products
 constexpr int KS1 = ME / 16;                 // 16-deep steps of the first product
 constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
 
@@ -125,9 +126,9 @@ __device__ __forceinline__ void weave() {
 
 template <bool HASR>
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * XSTAGE + HBYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NXS * XSTAGE + HBYTES];   // 160 KB: the whole LDS of the CU
     unsigned char* const xs = lds;
-    unsigned char* const hs = lds + 2 * XSTAGE;
+    unsigned char* const hs = lds + NXS * XSTAGE;
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
     typedef const __attribute__((address_space(1))) f16x8* gv8;
 
@@ -159,15 +160,23 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
         const int grow = min(m0 + row, p.M - 1);                     // rows past M re-read the last row (never stored)
         voff_x[i] = (unsigned)((((size_t)grow * 2 + (lc >> 3)) * ME + (lc & 7) * 8) * 2);
     }
-    auto dma_x = [&](int stage, int kt, int i0 = 0, int i1 = 8) {
+    // The DMA is issued as inline assembly ON PURPOSE: the compiler's wait-count pass knows that the builtin writes LDS and,
+    // unable to tell which bytes, puts `s_waitcnt vmcnt(0)` in front of the next LDS read -- which drained the weight
+    // prefetch ring and the DMA itself at EVERY 16-deep step of the first product (59 % of the matrix rate there against
+    // 92 % in the second product, whose steps follow no DMA).  The landing is guarded by hand: the counted vmcnt in front of
+    // each k-tile's barrier below.  (The hardware still counts these instructions in vmcnt, so the compiler's own counted
+    // waits for the weight fragments only ever wait longer than it thinks, never shorter.)
+    const unsigned xs_lds = (unsigned)(size_t)xs;                    // LDS byte address of the stage ring
+    auto dma_x = [&](unsigned stage_off, int kt, int i0 = 0, int i1 = 8) {
         const unsigned char* base = p.X + (size_t)kt * (BK * 2);     // uniform
         asm volatile("" : "+s"(base));          // an SGPR base per call: nothing per-lane and 64-bit is hoisted out of the loop
         const gptr g = (gptr)base;
 #pragma unroll
-        for (int i = i0; i < i1; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + voff_x[i]),
-                                             (__attribute__((address_space(3))) void*)(xs + stage * XSTAGE + (w * 8 + i) * 1024),
-                                             16, 0, 0);
+        for (int i = i0; i < i1; ++i) {
+            const gptr src = g + voff_x[i];
+            const unsigned dst = xs_lds + stage_off + (unsigned)((w * 8 + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+        }
     };
 
     // ---- weight fragments from L2: Wf[n / 32][k / 16][plane][lane] 16 bytes each (1 KiB per wave-instruction), in HALVES
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     f32x16 acc1[4];
 
     struct Frag { f16x8 v[4][2]; };                                  // token operand of one 16-deep step: [token block][plane]
-    auto read_x = [&](Frag& f, int stage, int s) {
-        const unsigned char* xb = xs + stage * XSTAGE + l31 * XROW;
+    auto read_x = [&](Frag& f, unsigned stage_off, int s) {
+        const unsigned char* xb = xs + stage_off + l31 * XROW;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -249,22 +258,23 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
         const float* b1c = p.b1 + c * HC + 32 * w + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1c + 8 * g);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1c + 8 * g) * SA;      // 2^8 b (exact)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f16x4 hi, lo;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    float v = fmaxf(acc1[i][4 * g + u] * (1.f / (SA * SW)) + bq[u], 0.f);
+                    // v = relu(acc 2^-18 + b); planes of 2^8 v (tocvp_store_planes4: clamp to the fp16 range, hi, residual).
+                    // 2^8 (acc 2^-18 + b) == acc 2^-10 + 2^8 b in fp32 (a power of two commutes with the rounding), and the
+                    // clamp to [0, 65504] is the ReLU and the saturation at once: same bits, half the instructions
+                    float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(acc1[i][4 * g + u], SA / (SA * SW), bq[u]), 0.f, 65504.f);
                     if (MABL == 3) {
                         hi[u] = (_Float16)0.f;
                         lo[u] = (_Float16)(v > 1e30f ? 1.f : 0.f);
                         continue;
                     }
-                    v = __builtin_amdgcn_fmed3f(v * SA, -65504.f, 65504.f);
                     hi[u] = (_Float16)v;
-                    v -= (float)hi[u];
-                    lo[u] = (_Float16)v;
+                    lo[u] = (_Float16)__builtin_fmaf((float)hi[u], -1.0f, v);     // v - hi, one rounding (v_fma_mix_f32)
                 }
                 unsigned char* row = hs + (32 * i + l31) * HROW + h * 8;
                 *reinterpret_cast<f16x4*>(row + (((unsigned)(4 * w + g) ^ x15) << 4)) = hi;
@@ -279,53 +289,63 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     unsigned long long st_g1 = 0, st_e1 = 0, st_g2 = 0;
 #endif
     MLP_STAMP(st_start);
-    dma_x(0, 0);
-    dma_x(1, 1);
+    // X stage ring (byte offsets): `st_rd` is read by the current k-tile g, `st_nx` holds g + 1, `st_fr` holds g + 2
+    // (landed or landing); behind the barrier of k-tile g its stage takes k-tile g + 3
+    unsigned st_rd = 0, st_nx = XSTAGE, st_fr = 2 * XSTAGE;
+    dma_x(st_rd, 0);
+    dma_x(st_nx, 1);
+    dma_x(st_fr, 2);
     load_w_half(wr[0], c_begin, 0);
     load_w_half(wr[1], c_begin, 1);
     load_w_half(wr[2], c_begin, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    read_x(F0, 0, 0);
+    read_x(F0, st_rd, 0);
 #pragma unroll 1
     for (int c = c_begin; c < c_end; ++c) {
+        const bool last = c + 1 == c_end;                            // no look-ahead past the end of this workgroup's range
         MLP_STAMP(s0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
         // ---- first product: 8 k-tiles of four 16-deep steps.  Entering k-tile kt: F0 = its step-0 token fragments,
-        // X k-tile kt + 1 on its way into the other stage, weight halves 2 kt .. 2 kt + 2 loaded or in flight.
+        // X k-tile kt + 1 on its way into (or landed in) st_nx, weight halves 2 kt .. 2 kt + 2 loaded or in flight.
 #pragma unroll
         for (int kt = 0; kt < ME / BK; ++kt) {
-            const int st = kt & 1, q = 2 * kt;
+            const int q = 2 * kt;
             if (MABL != 2) load_w_half(wr[(q + 3) & 3], c, q + 3);
-            if (MABL != 1) dma_x(st ^ 1, (kt + 1) & 7, DSPLIT, 8);   // the rest of k-tile kt + 1 (begun in the previous step)
-            read_x(F1, st, 1);
+            read_x(F1, st_rd, 1);
             if (MABL != 4) mfma1(F0, wr[q & 3], 0);
-            weave2<12, 8, 4 + (8 - DSPLIT)>();
+            weave<12, 8, 4>();
             __builtin_amdgcn_sched_barrier(0);
-            read_x(F0, st, 2);
+            read_x(F0, st_rd, 2);
             if (MABL != 4) mfma1(F1, wr[q & 3], 1);
             weave<12, 8, 0>();
             __builtin_amdgcn_sched_barrier(0);
             if (MABL != 2) load_w_half(wr[(q + 4) & 3], c, q + 4);
-            read_x(F1, st, 3);
+            read_x(F1, st_rd, 3);
             if (MABL != 4) mfma1(F0, wr[(q + 1) & 3], 0);
             weave<12, 8, 4>();
             __builtin_amdgcn_sched_barrier(0);
-            // every wave has read all of this stage (F1 landed) and its share of k-tile kt + 1 has landed: its last DMA
-            // instructions were issued in this k-tile's first step, 4 weight-fragment loads are younger
+            // every wave has read all of this stage (F1 landed) and its share of k-tile kt + 1 has landed: that DMA was
+            // issued behind the barrier of k-tile kt - 2; younger are the two weight halves (8) and the 8 DMA instructions
+            // (k-tile kt + 2) of k-tile kt - 1 and this k-tile's two weight halves (8)
             if (MABL != 5) {
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
             }
-            if (MABL != 1) dma_x(st, (kt + 2) & 7, 0, DSPLIT);       // k-tile kt + 2 (of the next chunk past the end) into this stage
-            if (kt + 1 < ME / BK) read_x(F0, st ^ 1, 0);
+            // k-tile kt + 3 (of the next chunk past the end) into the stage this k-tile has just finished reading
+            if (MABL != 1 && (kt + 3 < ME / BK || !last)) dma_x(st_rd, (kt + 3) & 7);
+            if (kt + 1 < ME / BK) read_x(F0, st_nx, 0);
             if (MABL != 4) mfma1(F1, wr[(q + 1) & 3], 1);
-            if (kt + 1 < ME / BK) weave2<12, 8, DSPLIT>();
-            else weave2<12, 0, DSPLIT>();
+            if (kt + 1 < ME / BK) weave2<12, 8, 8>();
+            else weave2<12, 0, 8>();
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned t_ = st_rd;
+            st_rd = st_nx;
+            st_nx = st_fr;
+            st_fr = t_;
         }
         MLP_STAMP(s1);
         epilogue1(c);
@@ -339,13 +359,13 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
             const int q = 16 + 2 * s;
             Frag& cur = (s & 1) ? F1 : F0;
             Frag& nxt = (s & 1) ? F0 : F1;
-            if (MABL != 2) load_w_half(wr[(q + 3) & 3], c, q + 3);
+            if (MABL != 2 && (q + 3 < 32 || !last)) load_w_half(wr[(q + 3) & 3], c, q + 3);
             if (s + 1 < HC / 16) read_h(nxt, s + 1);
-            else read_x(nxt, 0, 0);                                  // step 0 of the next chunk's first k-tile (landed long ago)
+            else read_x(nxt, st_rd, 0);                              // step 0 of the next chunk's first k-tile (landed long ago)
             if (MABL != 4) mfma2(cur, wr[q & 3], 0);
             weave<24, 8, 4>();
             __builtin_amdgcn_sched_barrier(0);
-            if (MABL != 2) load_w_half(wr[(q + 4) & 3], c, q + 4);
+            if (MABL != 2 && (q + 4 < 32 || !last)) load_w_half(wr[(q + 4) & 3], c, q + 4);
             if (MABL != 4) mfma2(cur, wr[(q + 1) & 3], 2);
             weave<24, 0, 4>();
             __builtin_amdgcn_sched_barrier(0);
@@ -422,31 +442,50 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
         }
     }
 
-    // ---- epilogue: register quad g of acc2[i][jt] = output columns 128 w + 32 jt + 8 g + 4 h .. + 3 of token 32 i + l31;
-    // the residual quads of an output tile are fetched together, ahead of its arithmetic
+    // ---- epilogue.  Register quad g of acc2[i][jt] = output columns 128 w + 32 jt + 8 g + 4 h .. + 3 of token 32 i + l31:
+    // stored as it stands, a wave-instruction would touch 32 rows x 32 bytes.  The tile goes through LDS instead (all of
+    // it is free now), 64 tokens at a time as fp32 rows of 512 + 4 floats, and leaves as whole rows: every load of the
+    // residual and every store covers 1 KiB of contiguous memory.
+    constexpr int OS = ME + 4;                                       // floats per staged row (16 B pad: conflict-free stores)
+    float* const ost = reinterpret_cast<float*>(lds);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                             // LDS free: the products / the previous half are done
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-        const int col0 = 128 * w + 32 * jt + 4 * h;
-        f32x4 rq[4][4];
-        if (HASR) {
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* rrow = p.R + (size_t)min(m0 + 32 * i + l31, p.M - 1) * p.ldr + col0;
+            for (int g = 0; g < 4; ++g) {
+                const int col = 128 * w + 32 * jt + 8 * g + 4 * h;
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(p.b2 + col);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rq[i][g] = *reinterpret_cast<const f32x4*>(rrow + 8 * g);
+                for (int ii = 0; ii < 2; ++ii) {
+                    // (static accumulator indices: both halves are spelled out)
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = (half == 0 ? acc2[ii][jt][4 * g + u] : acc2[2 + ii][jt][4 * g + u]) * (1.f / (SA * SW)) + bq[u];
+                    *reinterpret_cast<f32x4*>(ost + (32 * ii + l31) * OS + col) = v;
+                }
             }
-        }
+        __syncthreads();
+        // 64 rows x 128 quads; a wave-instruction = half a row (64 lanes x 16 B), 8 residual quads in flight per lane
+#pragma unroll 1
+        for (int it0 = 0; it0 < 32; it0 += 8) {
+            f32x4 rq[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(p.b2 + col0 + 8 * g);
+            for (int k = 0; k < 8; ++k) {
+                const int idx = t + 256 * (it0 + k);
+                const int row = m0 + 64 * half + (idx >> 7), c4 = (idx & 127) * 4;
+                if (HASR) rq[k] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(row, p.M - 1) * p.ldr + c4);
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + 32 * i + l31;
-                f32x4 v;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = acc2[i][jt][4 * g + u] * (1.f / (SA * SW)) + bq[u];
-                if (HASR) v += rq[i][g];
-                if (row < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)row * p.ldy + col0 + 8 * g) = v;
+            for (int k = 0; k < 8; ++k) {
+                const int idx = t + 256 * (it0 + k);
+                const int rl = idx >> 7, c4 = (idx & 127) * 4;
+                const int row = m0 + 64 * half + rl;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ost + rl * OS + c4);
+                if (HASR) v += rq[k];
+                if (row < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)row * p.ldy + c4) = v;
             }
         }
     }
