@@ -56,6 +56,9 @@
 #ifndef TOCVP_CONV_MFMA_ORDER
 #define TOCVP_CONV_MFMA_ORDER 1
 #endif
+#ifndef TOCVP_CONV_WDIST
+#define TOCVP_CONV_WDIST 2        // steps between a weight fragment's load and its first use (round 4: 2, four register slots)
+#endif
 #ifndef TOCVP_CONV_ROWREUSE
 #define TOCVP_CONV_ROWREUSE 1
 #endif
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                     (const __attribute__((address_space(1))) void*)(pbase + (unsigned)(i < 8 ? o0[i & 7] : o1[i & 7]) * 16u),
                     (__attribute__((address_space(3))) void*)(in_s + (i * 4 + wave) * 1024), 16, 0, 0);
             load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
+        if (TOCVP_CONV_ROWREUSE && TOCVP_CONV_WDIST >= 2) load_w(1, pass * NTAP + 5);    // ... and tap (1, 0)'s
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (outside) {
 #pragma unroll
@@ -253,13 +257,20 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
             }
         }
         load_w(0, pass * NTAP);                  // first tap's weights fly across the barrier
+        if (TOCVP_CONV_ROWREUSE && TOCVP_CONV_WDIST >= 2) load_w(1, pass * NTAP + 5);    // ... and tap (1, 0)'s
         __syncthreads();
         }
 
 #if TOCVP_CONV_ROWREUSE
         {
             f16x8 fa[2][2][2];                                      // [set][32-pixel half][plane]
-            f16x8 w3[3][2][2];                                      // rolling weights of tap rows q-1, q, q+1: [slot][plane][n]
+            // rolling weights: tap n = 5 dx + (tap row) lives in slot n % NSLOT from its load, WD steps ahead of its first
+            // use, to its second use one step later.  Round 3 loaded ONE step ahead (3 slots): in the compiled loop 16 of a
+            // pass's 96 fragment loads were consumed by the very next MFMA and half of them within 10 MFMAs (~320 cycles
+            // against an L2 round trip of 600+) -- each such wait stalls the wave, and only the partner wave of the SIMD
+            // covers it.  Two steps ahead (4 slots, +16 registers) puts 24-36 MFMAs between load and use.
+            constexpr int WD = TOCVP_CONV_WDIST, NSLOT = WD + 2;
+            f16x8 w3[NSLOT][2][2];                                  // [slot][plane][n]
             auto read_rows = [&](int set, int q, int dx) {
                 const unsigned char* a_base = in_s + (q * IW + dx) * ROWB;
 #pragma unroll
@@ -279,19 +290,23 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) w3[0][pl][n] = bw[0][pl][n];     // tap (0, 0) was fetched across the barrier
+                for (int n = 0; n < 2; ++n) {
+                    w3[0][pl][n] = bw[0][pl][n];                    // tap (0, 0) was fetched across the barrier
+                    if (WD >= 2) w3[1][pl][n] = bw[1][pl][n];       // ... and tap (1, 0)
+                }
             read_rows(0, 0, 0);
 #pragma unroll
             for (int st = 0; st < 30; ++st) {
                 const int dx = st / 6, q = st % 6, cur = st & 1;
                 int nw = 0, nr = 0;
-                if (q < 4) {                                        // weights of tap row q + 1, used from the next step on
-                    load_w3((q + 1) % 3, q + 1, dx);
-                    nw = 4;
-                } else if (q == 5 && dx < 4) {
-                    load_w3(0, 0, dx + 1);
-                    nw = 4;
+                {
+                    const int s2 = st + WD, dx2 = s2 / 6, q2 = s2 % 6;      // the tap first used WD steps from now
+                    if (s2 < 30 && q2 < 5) {
+                        load_w3((5 * dx2 + q2) % NSLOT, q2, dx2);
+                        nw = 4;
+                    }
                 }
+                const int s0 = (5 * dx + q) % NSLOT, s1 = (5 * dx + q + NSLOT - 1) % NSLOT;   // slots of tap rows q, q - 1
                 if (st + 1 < 30) {
                     read_rows(cur ^ 1, (st + 1) % 6, (st + 1) / 6);
                     nr = 4;
@@ -301,21 +316,21 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
 #if TOCVP_CONV_MFMA_ORDER
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh) {                // one operand stays put between neighbours
-                        acc[xh][0] = mfma16(fa[cur][xh][1], w3[q % 3][0][0], acc[xh][0]);      // Xl Wh0
-                        acc[xh][1] = mfma16(fa[cur][xh][1], w3[q % 3][0][1], acc[xh][1]);      // Xl Wh1
-                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[q % 3][1][1], acc[xh][1]);      // Xh Wl1
-                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[q % 3][1][0], acc[xh][0]);      // Xh Wl0
-                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[q % 3][0][0], acc[xh][0]);      // Xh Wh0
-                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[q % 3][0][1], acc[xh][1]);      // Xh Wh1
+                        acc[xh][0] = mfma16(fa[cur][xh][1], w3[s0][0][0], acc[xh][0]);      // Xl Wh0
+                        acc[xh][1] = mfma16(fa[cur][xh][1], w3[s0][0][1], acc[xh][1]);      // Xl Wh1
+                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[s0][1][1], acc[xh][1]);      // Xh Wl1
+                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[s0][1][0], acc[xh][0]);      // Xh Wl0
+                        acc[xh][0] = mfma16(fa[cur][xh][0], w3[s0][0][0], acc[xh][0]);      // Xh Wh0
+                        acc[xh][1] = mfma16(fa[cur][xh][0], w3[s0][0][1], acc[xh][1]);      // Xh Wh1
                     }
 #else
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
-                            acc[xh][n] = mfma16(fa[cur][xh][1], w3[q % 3][0][n], acc[xh][n]);      // Xl Wh
-                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][1][n], acc[xh][n]);      // Xh Wl
-                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[q % 3][0][n], acc[xh][n]);      // Xh Wh
+                            acc[xh][n] = mfma16(fa[cur][xh][1], w3[s0][0][n], acc[xh][n]);      // Xl Wh
+                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[s0][1][n], acc[xh][n]);      // Xh Wl
+                            acc[xh][n] = mfma16(fa[cur][xh][0], w3[s0][0][n], acc[xh][n]);      // Xh Wh
                         }
 #endif
                     nm += 12;
@@ -324,21 +339,21 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
 #if TOCVP_CONV_MFMA_ORDER
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh) {
-                        acc[2 + xh][0] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][0], acc[2 + xh][0]);
-                        acc[2 + xh][1] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][1], acc[2 + xh][1]);
-                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][1], acc[2 + xh][1]);
-                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][0], acc[2 + xh][0]);
-                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][0], acc[2 + xh][0]);
-                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][1], acc[2 + xh][1]);
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][1], w3[s1][0][0], acc[2 + xh][0]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][1], w3[s1][0][1], acc[2 + xh][1]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[s1][1][1], acc[2 + xh][1]);
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[s1][1][0], acc[2 + xh][0]);
+                        acc[2 + xh][0] = mfma16(fa[cur][xh][0], w3[s1][0][0], acc[2 + xh][0]);
+                        acc[2 + xh][1] = mfma16(fa[cur][xh][0], w3[s1][0][1], acc[2 + xh][1]);
                     }
 #else
 #pragma unroll
                     for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
-                            acc[2 + xh][n] = mfma16(fa[cur][xh][1], w3[(q - 1) % 3][0][n], acc[2 + xh][n]);
-                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][1][n], acc[2 + xh][n]);
-                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[(q - 1) % 3][0][n], acc[2 + xh][n]);
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][1], w3[s1][0][n], acc[2 + xh][n]);
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[s1][1][n], acc[2 + xh][n]);
+                            acc[2 + xh][n] = mfma16(fa[cur][xh][0], w3[s1][0][n], acc[2 + xh][n]);
                         }
 #endif
                     nm += 12;
