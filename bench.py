@@ -571,8 +571,11 @@ def main():
                 if rec.get("slot_images_per_launch") and cp in rec.get("kernel", ""):
                     traffic = rec["hbm_bytes_per_launch"] * (
                         conv["units"] / conv["launches"]) / rec["slot_images_per_launch"]
-                    traffic_from = "profiles/conv_pmc_summary.json (rocprofv3 PMC, separate FETCH_SIZE / " \
-                                   "WRITE_SIZE passes, gfx950 x2 fetch correction; not this run)"
+                    traffic_from = "profiles/conv_pmc_summary.json (rocprofv3 PMC on scripts/decode_only.py, separate " \
+                                   "FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; launch-weighted mean of " \
+                                   "the three instances the timed tree runs -- layer 1 collapsed input, layer 2 planes " \
+                                   "in / out, layer 3 planes in + folded tail out; " \
+                                   f"{rec.get('hbm_over_algorithmic', 0):.2f} x the algorithmic bytes; not this run)"
             roofline = {"bound": "mfma", "kernel": kernel_name,
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4),
