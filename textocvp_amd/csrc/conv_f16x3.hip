@@ -59,6 +59,12 @@
 #ifndef TOCVP_CONV_WDIST
 #define TOCVP_CONV_WDIST 2        // steps between a weight fragment's load and its first use (round 4: 2, four register slots)
 #endif
+#ifndef TOCVP_CONV_READS_FIRST
+#define TOCVP_CONV_READS_FIRST 0  // 1: every step fenced, the next step's operand reads behind its first MFMAs (22 instead of
+                                  // 4 MFMAs between an LDS read and its use, two fragment sets live) -- measured SLOWER: 3.92 against
+                                  // 3.60-3.65 ms per 2040 slot images in the bench (the fence stops the scheduler from overlapping
+                                  // neighbouring steps)
+#endif
 #ifndef TOCVP_CONV_ROWREUSE
 #define TOCVP_CONV_ROWREUSE 1
 #endif
@@ -358,6 +364,22 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
 #endif
                     nm += 12;
                 }
+#if TOCVP_CONV_READS_FIRST
+                // one memory instruction behind every MFMA: the operand reads of the NEXT step first (round 3 gave them the
+                // slots behind the weight loads, and a 12-MFMA step has only six two-MFMA slots: half of its reads were left
+                // to the scheduler, which put them right in front of their use -- median 4 MFMAs between an LDS read and the
+                // MFMA that consumes it, minimum 0), then the weight fragments used two steps from now
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    if (i >= nm) break;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
+                    if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // operand read
+                    else if (i - nr < nw) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // weight fragment load
+                }
+                // a step's reads and loads stay inside the step: without this fence the groups of step s + 1 capture the
+                // reads written in step s, which then land right in front of their use (one register set instead of two)
+                __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
                     if (2 * i >= nm) break;
@@ -365,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
                     if (i < nw) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // weight fragment load
                     else if (i - nw < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // operand read
                 }
+#endif
             }
         }
 #elif TOCVP_CONV_WEAVE
