@@ -45,7 +45,8 @@ _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "wide")
 # two alternations), -0.3 % without; same rows threshold; bit-identical
 _PRESPLIT_MLP = os.environ.get("TOCVP_PRESPLIT_MLP", "1") != "0"
 _PRESPLIT_MIN_N = 1536
-_PRESPLIT_MIN_ROWS = 16384    # B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster
+# B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster (round 3, two GEMMs per MLP)
+_PRESPLIT_MIN_ROWS = int(os.environ.get("TOCVP_PRESPLIT_MIN_ROWS", "16384"))
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
 # LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
 _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
