@@ -53,6 +53,8 @@ with torch.no_grad():
             kernels.linear = timed("linear", kernels.linear, lin_key)
             kernels.mha = timed("mha", kernels.mha, lambda q, k, v, *a, **kw: (tuple(q.shape), tuple(k.shape)))
             kernels.layer_norm = timed("layer_norm", kernels.layer_norm, lambda x, *a, **kw: (tuple(x.shape),))
+            kernels.mlp_fused = timed("mlp_fused", kernels.mlp_fused, lambda x, w1, *a, **kw: (x.planes.shape[0], w1.shape[0]))
+            kernels.xattn_collapsed = timed("xattn", kernels.xattn_collapsed, lambda x, *a, **kw: (tuple(x.shape),))
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

@@ -42,6 +42,21 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+# The rollout's chain of short kernels runs on a HIGH-priority stream (TOCVP_ROLLOUT_PRIORITY=0: the caller's stream), so that its
+# workgroups are dispatched ahead of the decoder's 16320-workgroup grids whenever a CU frees up.  Round 4, two alternations on
+# one box: B = 32 3449 / 3494 -> 3541 / 3556 frames/s (+2 %), B = 128 4008 / 4014 -> 4034 / 4029 (+0.5 %), B = 8 neutral
+# (host-bound).  (Round 3 measured the same idea neutral at B = 128 with the two-GEMM MLPs.)  Same kernels, same results.
+_ROLLOUT_PRIORITY = os.environ.get("TOCVP_ROLLOUT_PRIORITY", "1") != "0"
+_ROLLOUT_STREAMS = {}
+
+
+def _rollout_stream(device):
+    key = (device.type, device.index)
+    if key not in _ROLLOUT_STREAMS:
+        _ROLLOUT_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _ROLLOUT_STREAMS[key]
+
+
 def _reads_context_only(predictor, num_context):
     """
     True when the rollout provably reads ``slot_history[:, :num_context]`` and nothing behind it, so the frames behind
@@ -149,7 +164,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
 
         def decode_step(t, pred_t):
             ready = torch.cuda.Event()
-            ready.record(main)
+            ready.record(torch.cuda.current_stream())
             pred_t.record_stream(side)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
@@ -158,7 +173,16 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
                 else:
                     per_step[t] = decomp_model(mode="decode", slots=pred_t)
         side.wait_stream(main)                                    # decoder weights / caches / outputs are ready
-        pred_slots = predictor(slot_history, step_callback=decode_step, **others)
+        if _ROLLOUT_PRIORITY:
+            hp = _rollout_stream(slot_history.device)
+            hp.wait_stream(main)
+            slot_history.record_stream(hp)
+            with torch.cuda.stream(hp):
+                pred_slots = predictor(slot_history, step_callback=decode_step, **others)
+            main.wait_stream(hp)
+            pred_slots.record_stream(main)
+        else:
+            pred_slots = predictor(slot_history, step_callback=decode_step, **others)
         main.wait_stream(side)
         if not placed:
             imgs = torch.stack([d["recons_imgs"] for d in per_step], dim=1)          # (B, P, C, H, W)
