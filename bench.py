@@ -454,7 +454,8 @@ def main():
 
     # small batches: the same step (hot path + metric kernel) replayed from a captured HIP graph -- from Python the
     # ~2400 short launches of a step are host-bound (evaluator.GraphedEval; bit-identical to the eager call)
-    graphed = GraphedEval(savi, pred, NUM_CONTEXT, NUM_PREDS, epilogue=metric_rows)
+    graphed = GraphedEval(savi, pred, NUM_CONTEXT, NUM_PREDS, epilogue=metric_rows,
+                          overlap_decode=os.environ.get("TOCVP_GRAPH_OVERLAP", "0") != "0")
 
     def step_graphed(inp):
         videos, tokens, lengths, noise = inp

@@ -385,6 +385,13 @@ int tocvp_dec_tail_placed_f32(const float* x, const float* w, const float* bias,
  * targets = videos[:, ctx : ctx + P].clamp(0, 1) (05_evaluate_predictor.py:95) in one pass. */
 int tocvp_clamp01_rows_f32(const float* src, long src_row_stride, float* dst, long rows, long row_len, void* stream);
 
+/* dst[i0, i1, i2, 0:L] = src[i0, i1, i2, 0:L]: strided 4-d copy, strides in floats and independent on both sides; L, every
+ * stride and both bases multiples of 4 floats.  The index copies of the hot path (torch.cat / torch.stack / .contiguous() of
+ * window slices in predictor_wrapper.py:60-69 and text_cond_OCVP.py:96-113, the frame loop of SAVi.py:139-223) without a
+ * torch kernel. */
+int tocvp_copy4d_f32(const float* src, long ss0, long ss1, long ss2, float* dst, long ds0, long ds1, long ds2, int n0,
+                     int n1, int n2, int L, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Text-encoder front end (text_encoders.py:89-103): token + position embedding, LayerNorm
  * (eps), zero the rows of padding tokens (id 0).  tokens: int64 (B,L); out: (B,L,D), D == 128.

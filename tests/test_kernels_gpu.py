@@ -919,3 +919,24 @@ def test_mlp_fused_against_the_two_gemms(M, monkeypatch):
     assert err < max(2.0 * err2, 5e-6)
     wk = k._mlp_workspace(xd.device)[0]
     assert int(wk[:1024].view(torch.int32).abs().sum()) == 0
+
+
+def test_copy_strided_matches_torch_index_copies():
+    """ tocvp_copy4d_f32 behind kernels.copy_strided / contiguous / stack1: the window slices, last-frame slices, stacks and
+    the time-major copy of the frames that the hot path used to leave to torch.cat / torch.stack / .contiguous() """
+    k = _k()
+    g = torch.Generator().manual_seed(3)
+    hist = torch.randn(5, 20, 30, 128, generator=g).to(DEV)
+    assert torch.equal(k.contiguous(hist[:, 3:13]), hist[:, 3:13].contiguous())
+    assert torch.equal(k.contiguous(hist[:, -1]), hist[:, -1].contiguous())
+    buf = torch.zeros(5, 7, 30, 128, device=DEV)
+    k.copy_strided(hist[:, 4], buf[:, 2])
+    assert torch.equal(buf[:, 2], hist[:, 4]) and float(buf[:, :2].abs().sum()) == 0 and float(buf[:, 3:].abs().sum()) == 0
+    vids = torch.rand(3, 9, 3, 64, 64, generator=g).to(DEV)
+    assert torch.equal(k.contiguous(vids[:, 2:8].transpose(0, 1)), vids[:, 2:8].transpose(0, 1).contiguous())
+    toks = torch.randn(4, 300, 512, generator=g).to(DEV)
+    assert torch.equal(k.contiguous(toks.reshape(4, 10, 30, 512)[:, -1]), toks.reshape(4, 10, 30, 512)[:, -1].contiguous())
+    parts = [torch.randn(6, 7, 128, generator=g).to(DEV) for _ in range(4)]
+    assert torch.equal(k.stack1(parts), torch.stack(parts, dim=1))
+    with pytest.raises(k.TocvpError):
+        k.copy_strided(hist[..., :6], torch.empty(5, 20, 30, 6, device=DEV))        # runs of 6 floats: not 16-byte pieces

@@ -283,6 +283,24 @@ __global__ __launch_bounds__(256) void slot_init_kernel(const float* __restrict_
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 // max |x| of a tensor as the BIT PATTERN of the (non-negative) float: orders like an unsigned integer, so one
+// dst[i0, i1, i2, :L] = src[i0, i1, i2, :L] with independent strides (floats) on both sides and contiguous runs of L floats
+// (L % 4 == 0, every stride % 4 == 0, 16-byte aligned bases): the index copies of the hot path -- window slices, stacks,
+// the time-major copy of the frames -- without a torch kernel
+__global__ __launch_bounds__(256) void copy4d_kernel(const float* __restrict__ src, long ss0, long ss1, long ss2,
+                                                     float* __restrict__ dst, long ds0, long ds1, long ds2, int n1, int n2,
+                                                     int L4, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int l = (int)(i % L4);
+        long r = i / L4;
+        const int i2 = (int)(r % n2);
+        r /= n2;
+        const int i1 = (int)(r % n1);
+        const long i0 = r / n1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i0 * ss0 + i1 * ss1 + i2 * ss2 + 4 * l);
+        *reinterpret_cast<f32x4*>(dst + i0 * ds0 + i1 * ds1 + i2 * ds2 + 4 * l) = v;
+    }
+}
+
 // dst[r, :] = clamp(src[r * src_rs + :], 0, 1) for rows of row_len floats (row_len % 4 == 0, 16-byte aligned rows):
 // the evaluator's targets = videos[:, ctx : ctx + P].clamp(0, 1) in one pass over a row-strided slice
 __global__ __launch_bounds__(256) void clamp01_rows_kernel(const float* __restrict__ src, long src_rs,
@@ -478,5 +496,22 @@ extern "C" int tocvp_clamp01_rows_f32(const float* src, long src_row_stride, flo
     const long want = (total4 + 255) / 256;
     hipLaunchKernelGGL(clamp01_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, src_row_stride, dst, row_len / 4, total4);
+    return tocvp_launch_status();
+}
+
+/* dst[i0, i1, i2, 0:L] = src[i0, i1, i2, 0:L]: a strided 4-d copy (strides in floats, independent on both sides; L, every
+ * stride and both bases multiples of 4 floats).  Replaces the index copies torch would launch on the hot path
+ * (`torch.cat` / `torch.stack` / `.contiguous()` of window slices in predictor_wrapper.py:60-69, text_cond_OCVP.py:96-113,
+ * the frame loop of SAVi.py:139-223). */
+extern "C" int tocvp_copy4d_f32(const float* src, long ss0, long ss1, long ss2, float* dst, long ds0, long ds1, long ds2,
+                                int n0, int n1, int n2, int L, void* stream) {
+    TOCVP_CHECK_ARG(src && dst && n0 >= 0 && n1 >= 0 && n2 >= 0 && L >= 0 && (L & 3) == 0);
+    TOCVP_CHECK_ARG(((ss0 | ss1 | ss2 | ds0 | ds1 | ds2) & 3) == 0);
+    if (!tocvp_aligned16(src) || !tocvp_aligned16(dst)) return TOCVP_EALIGN;
+    const long total4 = (long)n0 * n1 * n2 * (L / 4);
+    if (total4 == 0) return TOCVP_OK;
+    const long want = (total4 + 255) / 256;
+    hipLaunchKernelGGL(copy4d_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, ss0, ss1, ss2, dst, ds0, ds1, ds2, n1, n2, L / 4, total4);
     return tocvp_launch_status();
 }

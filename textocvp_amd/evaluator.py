@@ -120,13 +120,21 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         enc = _encode_stream(videos.device)
         predicted = core.initializer(batch_size=B, **others)
         first, state = core.decomp_frames(videos, 0, num_context, predicted)
-        slot_ctx = torch.stack(first, dim=1)                          # (B, num_context, K, D)
+        from . import kernels as K
+        # (B, num_context + num_preds, K, D): the context frames now, the later frames from the third stream (no cat)
+        hist_full = torch.empty((B, n_all) + tuple(first[0].shape[1:]), device=first[0].device, dtype=torch.float32)
+        for i_, s_ in enumerate(first):
+            K.copy_strided(s_, hist_full[:, i_])
+        slot_ctx = K.contiguous(hist_full[:, :num_context])           # (B, num_context, K, D): what the rollout reads
         enc.wait_stream(main)
         videos.record_stream(enc)
         state.record_stream(enc)
+        hist_full.record_stream(enc)
         with torch.cuda.stream(enc):
             later, _ = core.decomp_frames(videos, num_context, n_all, state)
-            rest = torch.stack(later, dim=1)
+            for i_, s_ in enumerate(later):
+                K.copy_strided(s_, hist_full[:, num_context + i_])
+            rest = hist_full
         slot_history = slot_ctx                                       # what the rollout reads
     else:
         out_model = decomp_model(mode="decomp", x=videos, num_imgs=n_all, decode=False, **others)
@@ -198,7 +206,7 @@ def forward_eval(decomp_model, predictor, videos, num_context, num_preds, overla
         cur = torch.cuda.current_stream()
         cur.wait_stream(_encode_stream(videos.device))
         rest.record_stream(cur)
-        slot_history = torch.cat([slot_history, rest], dim=1)
+        slot_history = rest
     targets = videos[:, num_context:num_context + num_preds].to(pred_imgs.device)
     if targets.is_cuda and targets.dtype == torch.float32 and (C * H * W) % 4 == 0 and targets.data_ptr() % 16 == 0:
         from . import kernels as K

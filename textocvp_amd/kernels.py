@@ -78,6 +78,9 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
+                                        ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_clamp01_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
                                               ctypes.c_long, ctypes.c_void_p]),
     "tocvp_gemm_wfrag_ws_bytes": (ctypes.c_size_t, []),
@@ -440,6 +443,82 @@ def absmax(t):
     word = torch.empty(1, device=t.device, dtype=torch.int32)
     _check(lib().tocvp_absmax_f32(_ptr(tc), tc.numel(), _ptr(word), _stream()), "tocvp_absmax_f32")
     return struct.unpack("f", struct.pack("i", int(word.item())))[0]
+
+
+def _copy_plan(src, dst):
+    """ (sizes of <= 3 leading dims, src strides, dst strides, L) for tocvp_copy4d_f32, or None if the views do not fit """
+    shape = list(src.shape)
+    ss, ds = list(src.stride()), list(dst.stride())
+    # the innermost run that is contiguous on BOTH sides
+    L, d = 1, len(shape)
+    while d > 0 and ss[d - 1] == L and ds[d - 1] == L:
+        L *= shape[d - 1]
+        d -= 1
+    dims = [(shape[i], ss[i], ds[i]) for i in range(d) if shape[i] != 1]
+    merged = []
+    for n, a, b in dims:                                     # merge neighbours that are contiguous with each other
+        if merged and merged[-1][1] == n * a and merged[-1][2] == n * b:
+            m = merged.pop()
+            merged.append((m[0] * n, a, b))
+        else:
+            merged.append((n, a, b))
+    if len(merged) > 3 or L % 4 or any(a % 4 or b % 4 for _, a, b in merged):
+        return None
+    while len(merged) < 3:
+        merged.insert(0, (1, 0, 0))
+    return merged, L
+
+
+# TOCVP_LIB_COPIES=0: leave the index copies to torch (dst.copy_ / .contiguous() / torch.stack) -- A/B switch
+_LIB_COPIES = os.environ.get("TOCVP_LIB_COPIES", "1") != "0"
+_COPY_PLANS = {}
+
+
+def copy_strided(src, dst):
+    """ dst[...] = src[...] (same shape, fp32, same device) through tocvp_copy4d_f32; returns dst.  Views whose layout the
+    kernel does not take (more than three strided dimensions, runs that are not multiples of 4 floats) raise. """
+    if not _LIB_COPIES:
+        dst.copy_(src)
+        return dst
+    key = (src.shape, src.stride(), dst.stride())
+    plan = _COPY_PLANS.get(key)
+    if plan is None:
+        _dev_f32(src, "copy source"), _dev_f32(dst, "copy destination")
+        assert src.shape == dst.shape, (src.shape, dst.shape)
+        plan = _copy_plan(src, dst) if src.numel() else ([(0, 0, 0)] * 3, 0)
+        if plan is None:
+            raise TocvpError(f"copy_strided: unsupported views {tuple(src.shape)} {src.stride()} -> {dst.stride()}")
+        if len(_COPY_PLANS) < 4096:
+            _COPY_PLANS[key] = plan
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_cuda or not dst.is_cuda:
+        raise TocvpError("copy_strided: fp32 tensors on the GPU only")
+    (n0, a0, b0), (n1, a1, b1), (n2, a2, b2) = plan[0]
+    if n0 * n1 * n2 == 0:
+        return dst
+    code = lib().tocvp_copy4d_f32(src.data_ptr(), a0, a1, a2, dst.data_ptr(), b0, b1, b2, n0, n1, n2, plan[1], _stream())
+    if code:
+        _check(code, "tocvp_copy4d_f32")
+    return dst
+
+
+def contiguous(t):
+    """ t if it is contiguous, else a contiguous copy made by the library's strided copy (no torch kernel) """
+    if t.is_contiguous():
+        return t
+    if not _LIB_COPIES:
+        return t.contiguous()
+    return copy_strided(t, torch.empty(t.shape, device=t.device, dtype=t.dtype))
+
+
+def stack1(tensors):
+    """ torch.stack(tensors, dim=1) of equally shaped contiguous (B, ...) fp32 tensors through the strided copy """
+    if not _LIB_COPIES:
+        return torch.stack(tensors, dim=1)
+    B = tensors[0].shape[0]
+    out = torch.empty((B, len(tensors)) + tuple(tensors[0].shape[1:]), device=tensors[0].device, dtype=torch.float32)
+    for i, t_ in enumerate(tensors):
+        copy_strided(t_, out[:, i])
+    return out
 
 
 def clamp01_rows(src):

@@ -276,7 +276,7 @@ class MultiHeadSelfAttention(MetaAttention):
         w_kv = self._derived.get("w_kv", [self.k.weight, self.v.weight],
                                  lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
         kv = K.linear(x, w_kv)                                            # (B, T, 2E)
-        q = K.linear(x[:, T - n_last:].contiguous(), self.q.weight)       # (B, n_last, E)
+        q = K.linear(K.contiguous(x[:, T - n_last:]), self.q.weight)      # (B, n_last, E)
         o = K.mha(q, kv[..., :E], kv[..., E:], self.num_heads, (E // self.num_heads) ** -0.5)
         return K.linear(o, self.out_projection[0].weight, residual=residual_last)
 
@@ -448,7 +448,7 @@ class AdaptedEncoderBlock(TransformerBlock):
         evaluated on the n_last rows that are consumed.  Bit-for-bit the rows forward() would give.
         """
         B, T, E = x.shape
-        x_last = x[:, T - n_last:].contiguous()
+        x_last = K.contiguous(x[:, T - n_last:])
         y = self.attn.forward_last(_ln(x, self.layernorm_query), n_last, residual_last=x_last)
         z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
         return _mlp(_ln(z, self.layernorm_mlp), self.mlp, residual=y)

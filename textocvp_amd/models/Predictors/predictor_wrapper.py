@@ -5,6 +5,7 @@ Autoregressive rollout wrapper.  Reference: models/Predictors/predictor_wrapper.
 import torch
 import torch.nn as nn
 
+from ... import kernels as K
 from ..Blocks.model_utils import RangeGuard, refuse_replication
 
 __all__ = ["PredictorWrapper"]
@@ -57,16 +58,30 @@ class PredictorWrapper(nn.Module, RangeGuard):
         num_preds = num_preds if num_preds is not None else self.num_preds
         text_embeddings = self.encode_text_caption(**kwargs)
 
-        window = slot_history[:, :self.num_context].clone()
+        if not slot_history.is_cuda or slot_history.dtype != torch.float32 or slot_history.shape[-1] % 4:
+            raise K.TocvpError("PredictorWrapper: the rollout runs on the GPU in fp32 (no CPU path)")
+        # Window bookkeeping without torch kernels: every frame the window can hold lives in ONE buffer
+        # (B, num_context + num_preds, K, D); the window of step t is a slice of it, made contiguous by the library's
+        # strided copy (the reference concatenates and slices, predictor_wrapper.py:60-69, 143-153)
+        B, _, Ks, D = slot_history.shape
+        ctx = self.num_context
+        buf = torch.empty((B, ctx + num_preds, Ks, D), device=slot_history.device, dtype=torch.float32)
+        K.copy_strided(slot_history[:, :ctx], buf[:, :ctx])
         preds = []
         for t in range(num_preds):
+            # the first window is ALL context frames (:60); from then on the newest input_buffer_size frames (:143-153)
+            lo = max(0, ctx + t - self.input_buffer_size) if t else 0
+            window = K.contiguous(buf[:, lo:ctx + t])
             cur = self.predictor(slots=window, time_step=t, text_embeddings=text_embeddings)
-            nxt = slot_history[:, self.num_context + t] if self.teacher_force else cur
-            window = self._update_buffer_size(torch.cat([window, nxt.unsqueeze(1)], dim=1))
-            preds.append(cur)
+            nxt = slot_history[:, ctx + t] if self.teacher_force else cur
+            K.copy_strided(nxt, buf[:, ctx + t])
+            if self.teacher_force:
+                preds.append(cur)
             if step_callback is not None:
                 step_callback(t, cur)
-        return torch.stack(preds, dim=1)
+        if self.teacher_force:                         # the window holds ground-truth slots: the predictions are apart
+            return K.stack1(preds)
+        return K.contiguous(buf[:, ctx:])
 
     def encode_text_caption(self, **kwargs):
         caption = kwargs.get("caption_tokens", None)

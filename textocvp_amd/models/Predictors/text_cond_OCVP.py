@@ -93,7 +93,7 @@ class BaseTextOCVP(nn.Module):
         """ slots (B, w, K, D) window, text_embeddings (B, Lt, E) -> next slots (B, K, D) """
         require_inference(self)
         B, w, Ks, D = slots.shape
-        slots = slots.contiguous()
+        slots = K.contiguous(slots)
         text_kv = self.prepare_text(text_embeddings)
         with K.gemm_precision(self.gemm_precision, owner=(self, "gemm_precision")):
             tokens = K.linear(slots, self.mlp_in.weight, self.mlp_in.bias,
@@ -108,9 +108,9 @@ class BaseTextOCVP(nn.Module):
                 else:
                     tokens = blk(tokens, text_embeddings, text_kv=kv)
             if not self.last_layer_newest_frame_only or nblk == 0:
-                last = tokens.reshape(B, w, Ks, self.token_dim)[:, -1].contiguous()
+                last = K.contiguous(tokens.reshape(B, w, Ks, self.token_dim)[:, -1])
             return K.linear(last, self.mlp_out.weight, self.mlp_out.bias,
-                            residual=slots[:, -1].contiguous() if self.residual else None)
+                            residual=K.contiguous(slots[:, -1]) if self.residual else None)
 
 
 class TextOCVP_CustomTF(BaseTextOCVP):

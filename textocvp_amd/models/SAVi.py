@@ -101,7 +101,7 @@ class SAVi(nn.Module, RangeGuard):
         T = num_imgs
         predicted = self.initializer(batch_size=B, **kwargs)
         history, _ = self.decomp_frames(x, 0, T, predicted)
-        slot_history = torch.stack(history, dim=1)                      # (B, T, K, D)
+        slot_history = K.stack1(history)                                # (B, T, K, D)
 
         if decode:
             out = self.decode(slot_history.reshape(B * T, self.num_slots, self.slot_dim))
@@ -129,7 +129,8 @@ class SAVi(nn.Module, RangeGuard):
         x = x.to(dev)
         # time-major copy of the frames: (T, B, C, H, W), so that frame t of all samples is one
         # contiguous (B, N, 2D) k/v block for the slot-attention kernel
-        frames = x[:, t_begin:t_end].transpose(0, 1).contiguous()
+        frames = K.contiguous(x[:, t_begin:t_end].transpose(0, 1)) if x.dtype == torch.float32 else \
+            x[:, t_begin:t_end].transpose(0, 1).contiguous()
         T = t_end - t_begin
         chunk = max(1, self.max_encode_images // max(B, 1))
         sa = self.slot_attention
