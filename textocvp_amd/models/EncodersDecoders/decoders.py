@@ -61,7 +61,8 @@ class ConvDecoder(nn.Module):
         mods.append(nn.Conv2d(self.out_features, out_channels, kernel_size=3, stride=1, padding=1))
         self.decoder = nn.Sequential(*mods)
         self._derived = Derived()
-        self.max_slot_images = 2048          # slot images decoded per chunk (bounds HBM scratch)
+        # slot images decoded per chunk (bounds HBM scratch: ~2.7 MB per slot image)
+        self.max_slot_images = int(os.environ.get("TOCVP_DEC_MAX_SLOT_IMAGES", "2048"))
         # arithmetic of the 64->64 convs:
         #   "f16x3"  (default) split-fp16 operands, 3 f16 matrix products, ~2^-21 per product = fp32-class;
         #            the only split mode that holds the 1e-4 bar with margin on weights with an O(1) RGB
