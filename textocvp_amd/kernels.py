@@ -314,7 +314,11 @@ TIMER = None   # set to a LaunchTimer() to time launches (conv5x5_*, gemm_*, mha
 
 
 def _timed(name, units, fn):
-    return fn() if TIMER is None else TIMER.wrap(name, units, fn)
+    """ ``name`` may be a callable (evaluated only when a LaunchTimer is installed: the f-string of every launch's name costs
+    host time on a host-bound step) """
+    if TIMER is None:
+        return fn()
+    return TIMER.wrap(name() if callable(name) else name, units, fn)
 
 
 def lib():
@@ -341,12 +345,22 @@ def _check(code, what):
         raise TocvpError(f"{what} failed: {msg} ({code})")
 
 
+# Host side of a launch: the evaluation step at 8 sequences is ~2400 launches and HOST-bound (53 ms of Python against
+# 62 ms until the device is done, scripts/host_profile.py), so the per-launch helpers are the cheap forms: the raw current
+# stream from torch's C binding (torch.cuda.current_stream() builds a Stream object: 7 us of the ~20 us per launch), plain
+# integers for pointers (ctypes converts them under the c_void_p argtypes).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
 def _dev_f32(t, name):
@@ -648,7 +662,7 @@ _MLP_WS = {}
 
 
 def _mlp_workspace(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream())
     rec = _MLP_WS.get(key)
     if rec is None:
         nbytes = lib().tocvp_mlp_f16x3_fused_ws_bytes()
@@ -681,7 +695,7 @@ def mlp_fused(x, w1, b1, w2, b2, residual=None):
         assert r2.shape[0] == M and r2.is_contiguous()
     out = torch.empty((M, 512), device=w1.device, dtype=torch.float32)
     _, wk_ptr, wk_bytes = _mlp_workspace(w1.device)
-    _timed(f"mlp_fused_{M}x512x{Hd}", 4.0 * M * 512 * Hd, lambda: _check(
+    _timed(lambda: f"mlp_fused_{M}x512x{Hd}", 4.0 * M * 512 * Hd, lambda: _check(
         lib().tocvp_mlp_f16x3_fused_f32(_ptr(x.planes), _ptr(f1), _ptr(b1), _ptr(f2), _ptr(b2), _ptr(r2), 512, _ptr(out),
                                         512, M, 512, Hd, wk_ptr, wk_bytes, _stream()),
         "tocvp_mlp_f16x3_fused_f32"))
@@ -742,24 +756,24 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
             M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
         # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)
         ws = _split_weight(w, 22, frag="rows")
-        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
             lib().tocvp_gemm_f16planes_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
                                            int(bool(out_split)), N, M, N, K, int(act), _stream()),
             "tocvp_gemm_f16planes_f32"))
     elif frag_ok and nsplit == 22 and not pre_split and _GEMM_KSPLIT and M <= _GEMM_KSPLIT_MAX_ROWS:
         # few output tiles (small batches): split-K over idle CUs through a per-stream workspace
         ws = _split_weight(w, nsplit, frag=True)
-        st = torch.cuda.current_stream(w.device).cuda_stream
+        st = _stream()
         _, wk_ptr, wk_bytes = _ksplit_workspace(w.device, st)
-        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
             lib().tocvp_gemm_f16wfrag_ws_f32(_ptr(x2), K, _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(rowvec),
                                              int(rv_div), int(rv_mod), int(bool(rv_flip)), _ptr(out),
                                              int(bool(out_split)), N, M, N, K, int(act), wk_ptr,
-                                             wk_bytes, ctypes.c_void_p(st)),
+                                             wk_bytes, st),
             "tocvp_gemm_f16wfrag_ws_f32"))
     elif frag_ok:
         ws = _split_weight(w, nsplit, frag=True)
-        _timed(f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
             lib().tocvp_gemm_bf16wfrag_f32(_ptr(x2), int(pre_split), K, _ptr(ws), nsplit,
                                            _ptr(bias), _ptr(r2), N, _ptr(rowvec), int(rv_div),
                                            int(rv_mod), int(bool(rv_flip)), _ptr(out),
@@ -855,7 +869,7 @@ def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
         _check_f16_range(absmax(gamma) * E ** 0.5 + absmax(beta),
                          "collapsed cross-attention: bound of the LayerNorm output")
     y = torch.empty_like(x)
-    _timed(f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * LP, lambda: _check(
+    _timed(lambda: f"xattn_{B}x{Tq}x{Lt}", 4.0 * B * Tq * E * heads * LP, lambda: _check(
         lib().tocvp_xattn_collapsed_f32(_ptr(x), _ptr(gamma), _ptr(beta), float(eps), _ptr(Gf), _ptr(Hf), _ptr(bias),
                                         _ptr(y), B, Tq, E, int(heads), int(Lt), float(scale), _stream()),
         "tocvp_xattn_collapsed_f32"))
@@ -899,7 +913,7 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
         _check_f16_range(max(absmax(q), absmax(k), absmax(v)),
                          "attention q / k / v (f16x3 products)", owner=("kernels", "_ATTN_QK16"))
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
-    _timed(f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, lambda: _check(
+    _timed(lambda: f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, lambda: _check(
         fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
            dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32"))
     return o
@@ -929,7 +943,7 @@ def slot_attn_iter(q, k, v, scale, eps, attn_out=None, ws=None):
         _check_f16_range(max(absmax(q), absmax(k), absmax(v)), "slot attention q / k / v")
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
     # units = algorithmic HBM bytes: k and v read once (B * 2 * N * D * sizeof)
-    _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
+    _timed(lambda: f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
         lib().tocvp_slot_attn_iter_f32(_ptr(q), _ptr(k), _ptr(v), k.stride(1), _ptr(upd),
                                        _ptr(attn_out), B, Ks, N, D, float(scale), float(eps),
                                        _ptr(ws), ws.numel() * 4, _stream()),
@@ -951,7 +965,7 @@ def slot_attn_iter_planes(q, kv_planes, scale, eps, attn_out=None, ws=None):
         ws = slot_attn_workspace(B, N, q.device)
     assert ws.numel() * 4 >= lib().tocvp_slot_attn_ws_bytes(B, N)
     upd = torch.empty((B, Ks, D), device=q.device, dtype=torch.float32)
-    _timed(f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
+    _timed(lambda: f"slot_attn_{B}x{Ks}x{N}x{D}", 2.0 * B * N * D * 4, lambda: _check(
         lib().tocvp_slot_attn_iter_planes_f32(_ptr(q), _ptr(kv_planes), _ptr(upd), _ptr(attn_out), B, Ks, N, D,
                                               float(scale), float(eps), _ptr(ws), ws.numel() * 4, _stream()),
         "tocvp_slot_attn_iter_planes_f32"))

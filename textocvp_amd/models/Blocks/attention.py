@@ -62,6 +62,18 @@ class TextKV:
         self.kv, self.collapsed = kv, collapsed
 
 
+def _params(mod, build):
+    """ tuple of a module's parameters / constants for the hot path, cached in the module's __dict__: on a host-bound step
+    (8 sequences: 2400 launches from Python) nn.Module.__getattr__ and nn.Sequential.__getitem__ are a measurable share of
+    the time per launch (scripts/host_profile.py).  Parameter OBJECTS survive load_state_dict / .to() (their data is
+    replaced in place), so the tuple stays valid. """
+    p = mod.__dict__.get("_tocvp_params")
+    if p is None:
+        p = build(mod)
+        mod.__dict__["_tocvp_params"] = p
+    return p
+
+
 def _ln(x, ln, add=None, split=0):
     # planes only for the many-row products: the skinny GEMMs of small batches take fp32 input (split-K over idle CUs,
     # 64-deep k-tiles), mid-size ones measured slower with planes -- and small-batch results stay what they were
@@ -69,7 +81,8 @@ def _ln(x, ln, add=None, split=0):
     # its own, so the checked pass hands fp32 tensors to the consuming GEMM, which verifies them (same arithmetic)
     if split and (K._CHECK_RANGE or x.numel() // x.shape[-1] <= _PRESPLIT_MIN_ROWS):
         split = 0
-    return K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=add, split=split)
+    w, b, eps = _params(ln, lambda m: (m.weight, m.bias, m.eps))
+    return K.layer_norm(x, w, b, eps, add=add, split=split)
 
 
 def _ns(*dims, n_out=None):
@@ -88,17 +101,17 @@ def _ns(*dims, n_out=None):
 
 def _mlp(x, seq, residual):
     """ Linear -> ReLU -> Linear (+ residual), both epilogues fused into the GEMMs. """
-    ns = _ns(seq[0].weight.shape[0], seq[0].weight.shape[1], seq[2].weight.shape[0],
-             n_out=seq[2].weight.shape[0])
+    w1, b1, w2, b2 = _params(seq, lambda m: (m[0].weight, m[0].bias, m[2].weight, m[2].bias))
+    ns = _ns(w1.shape[0], w1.shape[1], w2.shape[0], n_out=w2.shape[0])
     if (_PRESPLIT_MLP and not ns and not K._CHECK_RANGE and K.active_nsplit() == 22 and math.prod(tuple(x.shape[:-1])) > _PRESPLIT_MIN_ROWS
-            and all(d % 64 == 0 for d in seq[0].weight.shape + seq[2].weight.shape[:1])):
+            and all(d % 64 == 0 for d in w1.shape + w2.shape[:1])):
         ns = 22                           # the hidden activation leaves the up-projection's epilogue as planes
-    if seq[0].bias is not None and seq[2].bias is not None and K.mlp_fused_ok(x, seq[0].weight, seq[2].weight):
+    if b1 is not None and b2 is not None and K.mlp_fused_ok(x, w1, w2):
         # the predictor's 512 -> 2048 -> 512 pairs at many rows: ONE kernel, the hidden activation stays on the CU
         # (csrc/mlp_fused.hip; bit-identical to the two GEMMs below on whole 128-row tiles)
-        return K.mlp_fused(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, residual=residual)
-    h = K.linear(x, seq[0].weight, seq[0].bias, act=K.ACT_RELU, out_split=ns)
-    return K.linear(h, seq[2].weight, seq[2].bias, residual=residual)
+        return K.mlp_fused(x, w1, b1, w2, b2, residual=residual)
+    h = K.linear(x, w1, b1, act=K.ACT_RELU, out_split=ns)
+    return K.linear(h, w2, b2, residual=residual)
 
 
 SD_PLANES = 128          # slot dim of the plane-input slot-attention kernel
@@ -256,13 +269,13 @@ class MultiHeadSelfAttention(MetaAttention):
         if kwargs.get("mask", None) is not None:
             raise NotImplementedError("attention masks are not used on the slot-rollout path")
         E = x.shape[-1]                                                   # tensor or SplitAct
-        w = self._derived.get(
-            "w_qkv", [self.q.weight, self.k.weight, self.v.weight],
-            lambda: torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous())
+        wq, wk, wv, wo, heads = _params(self, lambda m: (m.q.weight, m.k.weight, m.v.weight, m.out_projection[0].weight,
+                                                          m.num_heads))
+        w = self._derived.get("w_qkv", [wq, wk, wv], lambda: torch.cat([wq, wk, wv], 0).contiguous())
         qkv = K.linear(x, w)                                              # (B, T, 3E)
-        o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], self.num_heads,
-                  (E // self.num_heads) ** -0.5, out_split=_ns(E, n_out=self.out_projection[0].weight.shape[0]))
-        return K.linear(o, self.out_projection[0].weight, residual=residual)
+        o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, (E // heads) ** -0.5,
+                  out_split=_ns(E, n_out=wo.shape[0]))
+        return K.linear(o, wo, residual=residual)
 
 
     def forward_last(self, x, n_last, residual_last):
@@ -406,11 +419,11 @@ class TransformerDecoderBlock(nn.Module):
             if text_kv.collapsed is not None and K.active_nsplit() == 22 and not isinstance(queries, K.SplitAct):
                 # LayerNorm + query projection + attention over the caption + output projection + residual: ONE kernel
                 Gf, Hf, Lt = text_kv.collapsed
-                lnq = self.ln_cross_att_q
-                z = K.xattn_collapsed(queries, lnq.weight, lnq.bias, lnq.eps, Gf, Hf, self.cross_attn.out_projection.bias,
-                                      self.cross_attn.num_heads, Lt, self.cross_attn.dim_head ** -0.5)
-                return _mlp(_ln(z, self.ln_mlp, split=_ns(queries.shape[-1], self.mlp[0].weight.shape[0],
-                                                          n_out=self.mlp[0].weight.shape[0])), self.mlp, residual=z)
+                qw, qb, qeps, ob, heads, dh, lnm, mlp, hid = _params(self, lambda m: (
+                    m.ln_cross_att_q.weight, m.ln_cross_att_q.bias, m.ln_cross_att_q.eps, m.cross_attn.out_projection.bias,
+                    m.cross_attn.num_heads, m.cross_attn.dim_head, m.ln_mlp, m.mlp, m.mlp[0].weight.shape[0]))
+                z = K.xattn_collapsed(queries, qw, qb, qeps, Gf, Hf, ob, heads, Lt, dh ** -0.5)
+                return _mlp(_ln(z, lnm, split=_ns(queries.shape[-1], hid, n_out=hid)), mlp, residual=z)
             text_kv = text_kv.kv
         E = queries.shape[-1]
         z = self.cross_attn(None, query_embs=_ln(queries, self.ln_cross_att_q,
@@ -435,11 +448,11 @@ class AdaptedEncoderBlock(TransformerBlock):
 
     def forward(self, x, text_embeddings, text_kv=None):
         assert x.ndim == 3, f"Input 'x' must have 3 dims, but got {x.shape = }..."
-        E = self.embed_dim
-        y = self.attn(_ln(x, self.layernorm_query, split=_ns(E, n_out=3 * E)), residual=x)
-        z = self.condition_slots_given_caption(y, text_embeddings, text_kv=text_kv)
-        return _mlp(_ln(z, self.layernorm_mlp, split=_ns(E, self.mlp_size, n_out=self.mlp_size)), self.mlp,
-                    residual=y)
+        E, hid, lnq, attn, xblk, lnm, mlp = _params(self, lambda m: (
+            m.embed_dim, m.mlp_size, m.layernorm_query, m.attn, m.cross_attention, m.layernorm_mlp, m.mlp))
+        y = attn(_ln(x, lnq, split=_ns(E, n_out=3 * E)), residual=x)
+        z = xblk(queries=y, feats=text_embeddings, text_kv=text_kv)
+        return _mlp(_ln(z, lnm, split=_ns(E, hid, n_out=hid)), mlp, residual=y)
 
     def forward_last(self, x, text_embeddings, n_last, text_kv=None):
         """
