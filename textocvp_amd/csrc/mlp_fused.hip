@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
         for (int i = i0; i < i1; ++i) {
             const gptr src = g + voff_x[i];
             const unsigned dst = xs_lds + stage_off + (unsigned)((w * 8 + i) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+            // (s_nop 0: the wait state the ISA asks for between a write of M0 and an LDS-DMA that reads it -- the compiler puts the
+            // same nop behind its own M0 writes)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
         }
     };
 
