@@ -551,9 +551,9 @@ extern "C" int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_fr
     int n_full = tiles, S = 1;
     const int left = tiles % cus;
     if (ws && left > 0) {
-        // 2 or 4 slices: the last arriver alone adds the records of a tile, 256 KB each at one CU's share of the L2
+        // 2 to 4 slices: the last arriver alone adds the records of a tile, 256 KB each at one CU's share of the L2
         // bandwidth (~4 us per record; 16 slices measured ~65 us of reduction behind 25 us of products)
-        const int s = cus / left >= 4 ? 4 : (cus / left >= 2 ? 2 : 1);
+        const int s = cus / left >= 4 ? 4 : cus / left;          // 1 .. 4
         if (s >= 2 && s <= nchunk && left * s <= WS_RECORDS && left <= WS_CTR_BYTES / 4) {
             S = s;
             n_full = tiles - left;
