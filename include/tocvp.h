@@ -135,6 +135,19 @@ size_t tocvp_mlp_f16x3_fused_ws_bytes(void);
 int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_frag, const float* b1, const void* w2_frag,
                               const float* b2, const float* R, int ldr, float* Y, int ldy, int M, int E, int Hd,
                               void* ws, size_t ws_bytes, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * f16x3 GEMM with the activation chunk resident in LDS (round 4, csrc/gemm_f16c.hip): C = act(A W^T + bias) (+ R) for
+ * wide products (N % 512 == 0, K % 128 == 0) -- nn.Linear 1024 -> 1024 of the reference's MLPPatchDecoder
+ * (models/EncodersDecoders/decoders.py:264-307) and the wide projections of the predictor / ViT blocks
+ * (models/Blocks/attention.py:167-175).  A workgroup owns 128 rows x 512 outputs: the A operand is walked in 128-deep
+ * chunks (64 KB images, double buffered, LDS-DMA), the weights stream from L2 in fragment order straight into the MFMA
+ * operand registers.  Bit-identical to tocvp_gemm_bf16wfrag_f32 (nsplit 22, a_split = 1) on the same operands.
+ *   A_planes: (M, 2, K) fp16 planes of 2^8 a (any c_split producer); W_frag: tocvp_split_weights_frag_f16 of W (N, K);
+ *   bias (N) or NULL; R (M, N) row stride ldr or NULL (added after the activation); C: fp32 (M, N) row stride ldc, or
+ *   (c_split) fp16 planes (M, 2, N); act: TOCVP_ACT_NONE / RELU / GELU.  M * K * 4 < 2^32.
+ * ------------------------------------------------------------------------------------------- */
+int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
+                            void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream);
 int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
                             const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
                             int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);

@@ -1,0 +1,368 @@
+// Split-fp16 ("f16x3", fp32-class) GEMM with the ACTIVATION CHUNK RESIDENT IN LDS and the weights streamed from L2 in
+// MFMA-fragment order -- the loop of the fused MLP's second product (mlp_fused.hip) as a GEMM of its own:
+//
+//     C (M, N) = act(A W^T + bias) (+ R)        A as fp16 operand planes (M, 2, K) of 2^8 a, N % 512 == 0, K % 128 == 0
+//
+// replaces nn.Linear where both dimensions are wide (reference decoders.py:264-307 MLPPatchDecoder layers 1024 -> 1024,
+// the DINOv2 ViT projections behind timm_encoders.py:59-70, Blocks/attention.py:167-175).  The in-loop-split kernel
+// (gemm_bf16.hip) and the all-DMA planes kernel (gemm_f16p.hip) stage BOTH operands per 32 / 64-deep k-tile and reach
+// 30-40 % of the matrix rate; the fused MLP's second product reaches 92 % with this structure:
+//   * a workgroup owns 128 tokens x 512 outputs, 4 waves, ONE per SIMD (512 registers, 256 accumulators); wave w owns
+//     outputs [128 w, 128 w + 128) and all 128 tokens, so every weight fragment is fetched by exactly one wave, straight
+//     from L2 into the MFMA operand registers (fragment order Wf[n / 32][k / 16][plane][lane], a ring of four 24-MFMA
+//     halves three ahead) -- no LDS traffic and no barrier for W;
+//   * the token operand is walked in chunks of 128 k: a 64 KB image [token][plane 0: 128 k | plane 1: 128 k] with a
+//     source-side 16-byte-chunk swizzle, double buffered, filled by LDS-DMA (16 instructions of 1 KiB per wave and
+//     chunk, against 64 per wave for the same 384 MFMAs in the fused MLP's first product); ONE barrier per chunk;
+//   * MFMA operands swapped (D^T = W A^T): a lane holds 4 consecutive outputs of one token per register quad; the tile
+//     leaves through LDS as whole rows (1 KiB per wave-instruction), as fp32 or as the fp16 operand planes of the next
+//     split GEMM;
+//   * workgroup ids: the column tiles of one row tile take consecutive slots of ONE XCD (the A chunk is fetched from HBM
+//     once and served to the other column tiles by that XCD's L2).
+// Arithmetic is bit-identical to tocvp_gemm_bf16wfrag_f32 with f16x3 planes (same planes, same k order, products
+// a_hi w_lo + a_lo w_hi + a_hi w_hi per 16-deep step into one accumulator, same epilogue expressions).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128;                      // tokens per workgroup
+constexpr int BN = 512;                      // outputs per workgroup
+constexpr int CK = 128;                      // k per chunk
+constexpr int AROW = 512;                    // bytes per token in a chunk image: [plane 0: 128 k | plane 1: 128 k]
+constexpr int ABYTES = BM * AROW;            // 64 KB
+constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
+constexpr int OS = BN + 4;                   // floats per staged output row (16 B pad: conflict-free stores)
+constexpr int LDS_BYTES = 64 * OS * 4 > 2 * ABYTES ? 64 * OS * 4 : 2 * ABYTES;   // 132 096
+
+struct ChunkArgs {
+    const unsigned char* A;                  // (M, 2, K) fp16 planes of 2^8 a
+    const unsigned char* Wf;                 // fragment-order planes of 2^10 W (N, K)
+    const float* bias;
+    const float* R; int ldr;                 // residual (M, N) or nullptr
+    void* C; int ldc; int c_split;           // fp32 (M, N) row stride ldc, or fp16 planes (M, 2, N)
+    int M, N, K, act;
+    int row_tiles, col_tiles;
+};
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+#ifndef TOCVP_GC_ABLATE
+#define TOCVP_GC_ABLATE 0       // timing experiments: 1 no A DMA in the loop, 2 no W loads in the loop, 4 no MFMAs, 5 no epilogue,
+#endif                          // 6 epilogue without its global stores, 7 epilogue without the LDS staging
+constexpr int GABL = TOCVP_GC_ABLATE;
+#ifdef TOCVP_GC_STAMP
+__device__ unsigned long long tocvp_gc_stamps[4096 * 4];     // per workgroup: start, loop start, loop end, end (s_memtime)
+#define GC_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define GC_STAMP(v)
+#endif
+
+// NM MFMAs with NDS LDS reads and NVM vector-memory instructions issued in their shadow (see mlp_fused.hip)
+template <int NM, int NDS, int NVM>
+__device__ __forceinline__ void weave() {
+    constexpr int NMEM = NDS + NVM;
+    constexpr int SLOTS = NMEM < NM ? NMEM : NM;
+    constexpr int PER = SLOTS > 0 ? NM / SLOTS : NM;
+    int mem = 0;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        const int take = (NMEM - mem + (SLOTS - i) - 1) / (SLOTS - i);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < take) {
+                if (mem < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                ++mem;
+            }
+    }
+    if (NM - PER * SLOTS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * SLOTS, 0);
+}
+
+__device__ __forceinline__ float act_of(float v, int act) {
+    if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+// ACT / CSPLIT / HASR are compile-time: with run-time switches the write-out loop compiled into a branch ladder that
+// waits for every LDS read on its own
+template <int ACT, bool CSPLIT, bool HASR>
+__global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    typedef const __attribute__((address_space(1))) unsigned char* gptr;
+    typedef const __attribute__((address_space(1))) f16x8* gv8;
+
+    // ---- tile of this workgroup: ids run over groups of 8 row tiles x all column tiles; inside a group the id's low three
+    // bits (= the XCD it is dispatched to) pick the row tile and the column tiles follow each other on that XCD
+    const int per_group = 8 * p.col_tiles;
+    const int grp = (int)blockIdx.x / per_group, rem = (int)blockIdx.x % per_group;
+    const int rt = grp * 8 + (rem & 7), ct = rem >> 3;
+    if (rt >= p.row_tiles) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int KS = p.K / 16, nchunk = p.K / CK;
+    const int m0 = rt * BM, n0 = ct * BN;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned x15 = (unsigned)(l31 & 15);
+
+    // ---- A chunk by LDS-DMA: 64 instructions of 1 KiB (2 tokens x 512 B) per chunk, 16 per wave.  The LDS image is
+    // lane-linear; the conflict-free order comes from the SOURCE side: physical 16-byte chunk c of token r holds logical
+    // chunk c ^ (r & 15), logical chunk = plane * 16 + k / 8
+    unsigned voff_a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = 2 * (w * 16 + i) + (lane >> 5);
+        const int lc = (lane & 31) ^ (row & 15);
+        const int grow = min(m0 + row, p.M - 1);                     // rows past M re-read the last row (never stored)
+        voff_a[i] = (unsigned)((((size_t)grow * 2 + (lc >> 4)) * p.K + (lc & 15) * 8) * 2);
+    }
+    // (inline assembly on purpose: see mlp_fused.hip -- the compiler's wait-count pass would put vmcnt(0) in front of
+    // every LDS read behind a global_load_lds builtin; the landing is guarded by the counted wait in front of the
+    // chunk barrier)
+    const unsigned a_lds = (unsigned)(size_t)lds;
+    auto dma_a = [&](unsigned buf_off, int c, int i0, int i1) {
+        const unsigned char* base = p.A + (size_t)c * (CK * 2);      // uniform
+        asm volatile("" : "+s"(base));
+        const gptr g = (gptr)base;
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const gptr src = g + voff_a[i];
+            const unsigned dst = a_lds + buf_off + (unsigned)((w * 16 + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+        }
+    };
+
+    // ---- weight fragments from L2 in HALVES of 24 MFMAs: half q = output tiles 2 (q & 1), + 1 of 16-deep step q / 2
+    const int nb0 = n0 / 32 + 4 * w;
+    const int qmax = 2 * KS - 1;
+    auto load_w_half = [&](f16x8 (&b)[4], int q) {
+        q = min(q, qmax);                                            // past the end: a harmless re-load, never used
+        const int s = q >> 1, jt0 = (q & 1) * 2;
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) {
+            const unsigned char* base = p.Wf + ((size_t)(nb0 + jt0 + jl) * KS + s) * 2048;
+            asm volatile("" : "+s"(base));
+            const gptr g = (gptr)base + lane16;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) b[2 * jl + pl] = *(gv8)(g + pl * 1024);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Frag { f16x8 v[4][2]; };                                  // token operand of one 16-deep step: [token block][plane]
+    auto read_a = [&](Frag& f, unsigned buf_off, int s) {
+        const unsigned char* ab = lds + buf_off + l31 * AROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                f.v[i][pl] = *reinterpret_cast<const f16x8*>(ab + i * 32 * AROW + (((unsigned)(pl * 16 + 2 * s + h) ^ x15) << 4));
+    };
+    auto mfma2 = [&](const Frag& f, const f16x8 (&b)[4], int jt0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                acc[i][jt0 + jl] = mfma16(b[2 * jl + 1], f.v[i][0], acc[i][jt0 + jl]);     // act hi x w lo
+                acc[i][jt0 + jl] = mfma16(b[2 * jl + 0], f.v[i][1], acc[i][jt0 + jl]);     // act lo x w hi
+                acc[i][jt0 + jl] = mfma16(b[2 * jl + 0], f.v[i][0], acc[i][jt0 + jl]);     // act hi x w hi
+            }
+    };
+
+    f16x8 wr[4][4];                                                  // ring of weight-fragment halves, slot = half & 3
+    Frag F0, F1;
+    GC_STAMP(st_start);
+    dma_a(0, 0, 0, 16);
+    load_w_half(wr[0], 0);
+    load_w_half(wr[1], 1);
+    load_w_half(wr[2], 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_a(F0, 0, 0);
+    GC_STAMP(st_loop);
+    unsigned cur = 0, oth = ABYTES;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        // entering chunk c: its image is complete in `cur`, F0 = its step-0 fragments, every wave is done with `oth`
+        // (barrier in step 7 of the previous chunk): chunk c + 1 goes there, two DMA instructions per half in steps 0 .. 3
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int q = 16 * c + 2 * s;
+            Frag& fc = (s & 1) ? F1 : F0;
+            Frag& fn = (s & 1) ? F0 : F1;
+            if (GABL != 2) load_w_half(wr[(q + 3) & 3], q + 3);
+            if (GABL != 1 && s < 4 && more) dma_a(oth, c + 1, 4 * s, 4 * s + 2);
+            if (s < 7) {
+                read_a(fn, cur, s + 1);
+            } else {
+                // every wave holds its step-7 fragments (the last reads of `cur`) and its share of chunk c + 1 has landed:
+                // those DMA instructions were issued in steps 0 .. 3, at least 12 weight-fragment loads ago
+                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (more) read_a(fn, oth, 0);
+            }
+            if (GABL != 4) mfma2(fc, wr[q & 3], 0);
+            if (s < 4) weave<24, 8, 6>();
+            else weave<24, 8, 4>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (GABL != 2) load_w_half(wr[(q + 4) & 3], q + 4);
+            if (GABL != 1 && s < 4 && more) dma_a(oth, c + 1, 4 * s + 2, 4 * s + 4);
+            if (GABL != 4) mfma2(fc, wr[(q + 1) & 3], 2);
+            if (s < 4) weave<24, 0, 6>();
+            else weave<24, 0, 4>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned t_ = cur;
+        cur = oth;
+        oth = t_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the fragment loads past the end
+    GC_STAMP(st_loop_end);
+    if (GABL == 5) {
+        if (acc[0][0][0] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
+        return;
+    }
+
+    // ---- epilogue.  Register quad g of acc[i][jt] = outputs n0 + 128 w + 32 jt + 8 g + 4 h .. + 3 of token 32 i + l31.
+    // The tile goes through LDS, 64 tokens at a time as fp32 rows of 512 + 4 floats, and leaves as whole rows: every load
+    // of the residual and every store covers 1 KiB (fp32) / 512 B per plane of contiguous memory.
+    float* const ost = reinterpret_cast<float*>(lds);
+    // the wave's 128 bias values, one round trip for all of them (a load per quad inside the staging loop compiled into
+    // sixteen serial L2 round trips per half tile: 62 k of a tile's 186 k cycles)
+    f32x4 bq[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[jt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bq[jt][g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 128 * w + 32 * jt + 8 * g + 4 * h);
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                             // LDS free: the products / the previous half are done
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 128 * w + 32 * jt + 8 * g + 4 * h;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    // (static accumulator indices: both halves are spelled out; the activation is applied on the way out)
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = (half == 0 ? acc[ii][jt][4 * g + u] : acc[2 + ii][jt][4 * g + u]) * (1.f / (SA * SW)) + bq[jt][g][u];
+                    if (GABL != 7) *reinterpret_cast<f32x4*>(ost + (32 * ii + l31) * OS + col) = v;
+                    else if (v[0] == 123.456f) ost[0] = 1.f;
+                }
+            }
+        __syncthreads();
+        // 64 rows x 128 quads; a wave-instruction = half a row (64 lanes x 16 B), 8 residual quads in flight per lane
+#pragma unroll 1
+        for (int it0 = 0; it0 < 32; it0 += 8) {
+            f32x4 rq[8], vq[8];
+            if (HASR) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = t + 256 * (it0 + k);
+                    const int row = m0 + 64 * half + (idx >> 7), c4 = (idx & 127) * 4;
+                    rq[k] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(row, p.M - 1) * p.ldr + n0 + c4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = t + 256 * (it0 + k);
+                vq[k] = f32x4{1.f, 2.f, 3.f, 4.f};
+                if (GABL != 7) vq[k] = *reinterpret_cast<const f32x4*>(ost + (idx >> 7) * OS + (idx & 127) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = t + 256 * (it0 + k);
+                const int rl = idx >> 7, c4 = (idx & 127) * 4;
+                const int row = m0 + 64 * half + rl;
+                f32x4 v = vq[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = act_of(v[u], ACT);
+                if (HASR) v += rq[k];
+                if (GABL == 6) {
+                    if (v[0] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
+                } else if (row < p.M) {
+                    if (CSPLIT) tocvp_store_planes4(p.C, (size_t)row * 2 * p.N + n0 + c4, (size_t)p.N, v, 22);
+                    else *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + n0 + c4) = v;
+                }
+            }
+        }
+    }
+#ifdef TOCVP_GC_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0 && blockIdx.x < 4096) {
+        unsigned long long* st = tocvp_gc_stamps + blockIdx.x * 4;
+        st[0] = st_start; st[1] = st_loop; st[2] = st_loop_end; st[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+}  // namespace
+
+#ifdef TOCVP_GC_STAMP
+extern "C" int tocvp_gc_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tocvp_gc_stamps), (size_t)n * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
+                                       void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream) {
+    TOCVP_CHECK_ARG(A_planes && W_frag && C && M >= 0 && N > 0 && K > 0);
+    TOCVP_CHECK_ARG((N % BN) == 0 && (K % CK) == 0);
+    TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
+    TOCVP_CHECK_ARG(c_split || (ldc >= N && (ldc & 3) == 0));
+    TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0));
+    TOCVP_CHECK_ARG((size_t)M * 2 * K * 2 < 0xffffffffull);        // 32-bit DMA source offsets
+    if (!tocvp_aligned16(A_planes) || !tocvp_aligned16(W_frag) || !tocvp_aligned16(C) || (bias && !tocvp_aligned16(bias)) ||
+        (R && !tocvp_aligned16(R)))
+        return TOCVP_EALIGN;
+    if (M == 0) return TOCVP_OK;
+    const int row_tiles = (M + BM - 1) / BM, col_tiles = N / BN;
+    ChunkArgs p{static_cast<const unsigned char*>(A_planes), static_cast<const unsigned char*>(W_frag), bias, R, ldr, C, ldc,
+                c_split, M, N, K, act, row_tiles, col_tiles};
+    const long groups = (row_tiles + 7) / 8;
+    TOCVP_CHECK_ARG(groups * 8 * col_tiles < 0x7fffffffL);
+    const dim3 grid((unsigned)(groups * 8 * col_tiles));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GC_LAUNCH(A_, S_, R_) hipLaunchKernelGGL((gemm_f16x3_chunk_kernel<A_, S_, R_>), grid, dim3(256), 0, st, p)
+#define GC_LAUNCH_SR(A_)                                  \
+    do {                                                  \
+        if (c_split) {                                    \
+            if (R) GC_LAUNCH(A_, true, true);             \
+            else GC_LAUNCH(A_, true, false);              \
+        } else {                                          \
+            if (R) GC_LAUNCH(A_, false, true);            \
+            else GC_LAUNCH(A_, false, false);             \
+        }                                                 \
+    } while (0)
+    if (act == TOCVP_ACT_RELU) GC_LAUNCH_SR(TOCVP_ACT_RELU);
+    else if (act == TOCVP_ACT_GELU) GC_LAUNCH_SR(TOCVP_ACT_GELU);
+    else GC_LAUNCH_SR(TOCVP_ACT_NONE);
+#undef GC_LAUNCH_SR
+#undef GC_LAUNCH
+    return tocvp_launch_status();
+}

@@ -78,6 +78,9 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_size_t, ctypes.c_void_p]),
+    "tocvp_gemm_f16chunk_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -443,6 +446,10 @@ _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment o
 # default plane inputs go to the two-workgroups-per-CU planes kernel of gemm_bf16.hip (gemm_f16_planes_kernel; small
 # shapes: the in-loop kernel's ASPLIT form), which shares a CU with the decoder's workgroups
 _GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
+# chunk-resident f16x3 GEMM (gemm_f16c.hip) for plane inputs with N % 512 == 0, K % 128 == 0 (TOCVP_GEMM_CHUNK=0: off)
+_GEMM_CHUNK = os.environ.get("TOCVP_GEMM_CHUNK", "0") != "0"
+_GEMM_CHUNK_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_ROWS", "16384"))
+_GEMM_CHUNK_MIN_K = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_K", "512"))
 _GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
@@ -752,7 +759,15 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         if not pre_split:
             _check_f16_range(absmax(x2), f"f16x3 GEMM ({M}x{N}x{K}) activation")
         _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
-    if (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
+    if (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and rowvec is None and N % 512 == 0 and K % 128 == 0 and
+            M >= _GEMM_CHUNK_MIN_ROWS and K >= _GEMM_CHUNK_MIN_K and M * 4 * K < 2 ** 32 and act in (ACT_NONE, ACT_RELU, ACT_GELU)):
+        # A chunks resident in LDS, weights streamed in fragment order (gemm_f16c.hip)
+        ws = _split_weight(w, 22, frag=True)
+        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+            lib().tocvp_gemm_f16chunk_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
+                                          int(bool(out_split)), N, M, N, K, int(act), _stream()),
+            "tocvp_gemm_f16chunk_f32"))
+    elif (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
             M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
         # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)
         ws = _split_weight(w, 22, frag="rows")

@@ -13,6 +13,11 @@ from ...precision import knob
 from ..Blocks.model_blocks import ConvBlock
 from ..Blocks.model_utils import Derived
 
+# MLPPatchDecoder: hidden activations between its Linear layers as producer-written fp16 operand planes
+# (TOCVP_DINO_MLP_PLANES=0 restores the fp32 hand-over); the all-DMA planes GEMM takes them when TOCVP_GEMM_P2 is on
+_MLP_PLANES = os.environ.get("TOCVP_DINO_MLP_PLANES", "0") != "0"
+_MLP_PLANES_MIN_ROWS = int(os.environ.get("TOCVP_DINO_MLP_PLANES_MIN_ROWS", "16384"))
+
 __all__ = ["get_decoder", "ConvDecoder", "MLPPatchDecoder"]
 
 
@@ -348,8 +353,14 @@ class MLPPatchDecoder(nn.Module):
         # 37 GFLOP per frame at config 4: f16x3 split operands (fp32-class) for the layers whose
         # shapes fit the fragment-order kernel; the 769-wide head stays on the exact fp32 MFMA
         with K.gemm_precision(self.mlp_precision, owner=(self, "mlp_precision")):
+            # hidden activations handed from layer to layer as fp16 operand planes written by the producing
+            # epilogue (the split the consumer would compute while staging: bit-identical); the checked pass
+            # keeps fp32 hand-overs so that every activation is verified by its consumer
+            planes = (_MLP_PLANES and K.active_nsplit() == 22 and not K._CHECK_RANGE and
+                      x.numel() // x.shape[-1] >= _MLP_PLANES_MIN_ROWS and
+                      all(l.weight.shape[0] % 32 == 0 and l.weight.shape[1] % 64 == 0 for l in linears[:-1]))
             for j, lin in enumerate(linears[:-1]):
-                x = K.linear(x, lin.weight, lin.bias, act=K.ACT_RELU)
+                x = K.linear(x, lin.weight, lin.bias, act=K.ACT_RELU, out_split=22 if planes else 0)
             # the head is out_dim = F + 1 wide (769): zero-padded to a multiple of 32 so that it runs
             # the split kernel too; the compositing kernel skips the padding columns
             head = linears[-1]
