@@ -137,7 +137,7 @@ int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_frag, const f
                               void* ws, size_t ws_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * f16x3 GEMM with the activation chunk resident in LDS (round 4, csrc/gemm_f16c.hip): C = act(A W^T + bias) (+ R) for
- * wide products (N % 512 == 0, K % 128 == 0) -- nn.Linear 1024 -> 1024 of the reference's MLPPatchDecoder
+ * wide products (N % 512 == 0 or N % 384 == 0, K % 128 == 0) -- nn.Linear 1024 -> 1024 of the reference's MLPPatchDecoder
  * (models/EncodersDecoders/decoders.py:264-307) and the wide projections of the predictor / ViT blocks
  * (models/Blocks/attention.py:167-175).  A workgroup owns 128 rows x 512 outputs: the A operand is walked in 128-deep
  * chunks (64 KB images, double buffered, LDS-DMA), the weights stream from L2 in fragment order straight into the MFMA

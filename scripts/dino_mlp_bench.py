@@ -4,7 +4,7 @@ MLPPatchDecoder (BASELINE configs[3], reference decoders.py:264-307) -- its four
 (16 frames x 24 slots x 256 patches = 98304 rows; 128 -> 1024 -> 1024 -> 1024 -> 769) under the hand-over variants:
   fp32      fp32 activations, split in the consumer's k-loop (gemm_bf16_wfrag_kernel)
   planes    fp16 operand planes written by the producing epilogue, in-loop kernel's plane-input form
-  planes+p2 the same planes into the all-DMA persistent planes GEMM (gemm_f16_planes3_kernel)
+  planes+chunk the same planes into the chunk-resident persistent GEMM (gemm_f16c.hip)
 Prints the time per forward of the MLP chain (HIP events, interleaved rounds) and checks the variants bit for bit.
 """
 import os, sys, torch
@@ -21,11 +21,11 @@ dec = model.decoder.cuda()
 dec.reconstruct_images = False
 slots = synth.synth_noise(frames, 24, 128, seed=5).cuda()
 
-VARIANTS = {"fp32": (False, False), "planes": (True, False), "planes+p2": (True, True)}
+VARIANTS = {"fp32": (False, False), "planes": (True, False), "planes+chunk": (True, True)}
 
 
 def run(name):
-    D._MLP_PLANES, K._GEMM_P2 = VARIANTS[name]
+    D._MLP_PLANES, K._GEMM_CHUNK = VARIANTS[name]
     with torch.no_grad():
         return dec(slots)
 

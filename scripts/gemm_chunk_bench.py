@@ -34,7 +34,7 @@ def as_planes(x):
 
 
 def run(x_planes, w, b, act, r, out_split, chunk):
-    K._GEMM_CHUNK, K._GEMM_CHUNK_MIN_ROWS, K._GEMM_CHUNK_MIN_K = chunk, 1, 128
+    K._GEMM_CHUNK, K._GEMM_CHUNK_MIN_TILES = chunk, 1
     with K.gemm_precision("f16x3"):
         y = K.linear(x_planes, w, b, act=act, residual=r, out_split=out_split)
     return y.planes if out_split else y
@@ -43,7 +43,7 @@ def run(x_planes, w, b, act, r, out_split, chunk):
 if mode in ("check", "all"):
     bad = 0
     for (M, N, Kd) in [(4096, 1024, 1024), (1000, 512, 128), (300, 512, 512), (128 * 9 + 5, 1536, 512), (2048, 2048, 2048),
-                       (77, 1024, 3072)]:
+                       (77, 1024, 3072), (1500, 768, 768), (700, 2304, 768), (260, 384, 128), (3000, 768, 3072)]:
         x, w, b, r, _ = operands(M, N, Kd)
         xp = as_planes(x)
         for act in (K.ACT_NONE, K.ACT_RELU, K.ACT_GELU):
@@ -67,7 +67,7 @@ if mode in ("check", "all"):
 
 if mode in ("time", "all"):
     shapes = [(98304, 1024, 1024), (98304, 1024, 128), (38400, 1536, 512), (38400, 2048, 512), (38400, 512, 2048),
-              (38400, 512, 512), (65792, 3072, 768), (9600, 1536, 512), (9600, 2048, 512), (9600, 512, 2048)]
+              (38400, 512, 512), (65792, 3072, 768), (65792, 2304, 768), (65792, 768, 3072), (9600, 1536, 512), (9600, 2048, 512), (9600, 512, 2048)]
     for (M, N, Kd) in shapes:
         x, w, b, r, _ = operands(M, N, Kd, dense=False)
         xp = as_planes(x)

@@ -49,18 +49,15 @@ for var in (0, 1, 2, 4, 5, 6, 7):
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / reps * 1e3)
-    n = min(tiles, 4096)
+    n = 256
     buf = (ctypes.c_ulonglong * (4 * n))()
     lib.tocvp_gc_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert lib.tocvp_gc_read_stamps(buf, n) == 0
     st = torch.tensor(list(buf), dtype=torch.float64).reshape(n, 4)
     st = st[st[:, 3] > 0]
-    if st.shape[0] == 0:
-        print(f'variant {var}: {best:.0f} us'); continue
-    pro, loop, epi, tot = (st[:, 1] - st[:, 0]), (st[:, 2] - st[:, 1]), (st[:, 3] - st[:, 2]), (st[:, 3] - st[:, 0])
-    span = st[:, 3].max() - st[:, 0].min()
-    # s_memtime counts at 100 MHz on gfx950: report in its ticks and as a share of the workgroup's life
-    print(f"variant {var}: {best:.0f} us ({2.0 * M * N * Kd / best / 1e6:.0f} TF/s) | per workgroup (memtime ticks, mean): "
-          f"prologue {pro.mean():.0f}, loop {loop.mean():.0f}, epilogue {epi.mean():.0f}, total {tot.mean():.0f}; "
-          f"shares {pro.mean() / tot.mean():.3f} / {loop.mean() / tot.mean():.3f} / {epi.mean() / tot.mean():.3f}; "
-          f"launch span {span:.0f} ticks", flush=True)
+    per = tiles / max(st.shape[0], 1)                # tiles per (persistent) workgroup
+    pro, loop, epi, tot = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+    print(f"variant {var}: {best:.0f} us ({2.0 * M * N * Kd / best / 1e6:.0f} TF/s) | {st.shape[0]} workgroups x {per:.2f} tiles; "
+          f"cycles per workgroup (mean): prologue {pro.mean():.0f}, k-loops {loop.mean():.0f} ({loop.mean() / per:.0f} per tile), "
+          f"epilogues {epi.mean():.0f} ({epi.mean() / per:.0f} per tile), life {tot.mean():.0f} (max {tot.max():.0f}) "
+          f"= {tot.max() / best / 1e3:.2f} GHz-equivalent", flush=True)

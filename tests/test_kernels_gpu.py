@@ -736,6 +736,7 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
     k = _k()
     monkeypatch.setattr(k, "_GEMM_P2", True)                    # the persistent planes kernel is opt-in
     monkeypatch.setattr(k, "_GEMM_P2_MIN_ROWS", 1)              # every plane-input product on the planes kernel
+    monkeypatch.setattr(k, "_GEMM_CHUNK", False)                # (not on the round-4 chunk-resident kernel)
     x = rnd("p3x", (M, Kd), "normal")
     w = rnd("p3w", (N, Kd), "uniform", Kd ** -0.5)
     b = rnd("p3b", (N,), "uniform", 0.1)
@@ -940,3 +941,68 @@ def test_copy_strided_matches_torch_index_copies():
     assert torch.equal(k.stack1(parts), torch.stack(parts, dim=1))
     with pytest.raises(k.TocvpError):
         k.copy_strided(hist[..., :6], torch.empty(5, 20, 30, 6, device=DEV))        # runs of 6 floats: not 16-byte pieces
+
+
+@pytest.mark.parametrize("M,N,Kd", [(4096, 1024, 1024), (1157, 1536, 512), (1000, 512, 128), (77, 1024, 3072),
+                                    (1500, 768, 768), (700, 2304, 768), (260, 384, 128)])
+def test_gemm_chunk_resident_equals_the_in_loop_split_kernel(M, N, Kd, monkeypatch):
+    """
+    csrc/gemm_f16c.hip (tocvp_gemm_f16chunk_f32): the persistent f16x3 GEMM whose A operand is walked in 128-deep chunks
+    resident in LDS while the weights stream from L2 in fragment order -- nn.Linear 1024 -> 1024 of the MLPPatchDecoder
+    (reference decoders.py:264-307) and the wide projections of the ViT / predictor blocks (attention.py:167-175).  Same
+    operand planes, same k order, same epilogue expressions as tocvp_gemm_bf16wfrag_f32: BIT-IDENTICAL for fp32 and plane
+    outputs, every activation, with and without the residual, on ragged row counts, for 512- and 384-wide column tiles
+    (N % 512 == 0 / N % 384 == 0); fp32-class against float64; repeatable.
+    """
+    k = _k()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, Kd, generator=g)
+    w, b = torch.randn(N, Kd, generator=g) / Kd ** 0.5, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    xd, wd, bd, rd = (t.to(DEV) for t in (x, w, b, r))
+    monkeypatch.setattr(k, "_GEMM_CHUNK_MIN_TILES", 1)
+    # the activation as fp16 operand planes of 2^8 x (the expressions of tocvp_store_planes4)
+    v = torch.clamp(xd * 256.0, -65504.0, 65504.0)
+    hi = v.to(torch.float16)
+    xp = k.SplitAct(torch.stack([hi, (v - hi.float()).to(torch.float16)], dim=1).contiguous(), (M, Kd))
+    with k.gemm_precision("f16x3"):
+        for act in (k.ACT_NONE, k.ACT_RELU, k.ACT_GELU):
+            for res, osplit in ((None, 0), (rd, 0), (None, 22)):
+                monkeypatch.setattr(k, "_GEMM_CHUNK", False)
+                a = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                monkeypatch.setattr(k, "_GEMM_CHUNK", True)
+                names = []
+                k.TIMER = type("T", (), {"wrap": staticmethod(lambda name, units, fn: (names.append(name), fn())[1])})()
+                try:
+                    c = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                    c2 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit, chunk_ok=False)
+                finally:
+                    k.TIMER = None
+                assert len(names) == 2
+                if osplit:
+                    a, c, c2 = a.planes.view(torch.int16), c.planes.view(torch.int16), c2.planes.view(torch.int16)
+                assert torch.equal(a, c), (act, res is not None, osplit)
+                assert torch.equal(a, c2)
+        got = k.linear(xp, wd, bd)
+        assert torch.equal(got, k.linear(xp, wd, bd))
+    ref = x.double() @ w.double().t() + b.double()
+    err = (got.cpu().double() - ref).abs().max().item()
+    print(f"chunk-resident GEMM {M}x{N}x{Kd}: {err:.2e} vs float64 (max |y| {ref.abs().max().item():.1f})")
+    assert err < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_chunk_resident_rejects_bad_arguments():
+    k = _k()
+    lib = k.lib()
+    a = torch.zeros(256, 2, 128, device=DEV, dtype=torch.float16)
+    w = torch.zeros(512 * 2 * 128, device=DEV, dtype=torch.float16)
+    c = torch.zeros(256, 512, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ok = lib.tocvp_gemm_f16chunk_f32(a.data_ptr(), w.data_ptr(), None, None, 0, c.data_ptr(), 0, 512, 256, 512, 128, 0, st)
+    assert ok == 0
+    for (N, Kd, act, ldc) in ((500, 128, 0, 512), (512, 100, 0, 512), (512, 128, 7, 512), (512, 128, 0, 256)):
+        assert lib.tocvp_gemm_f16chunk_f32(a.data_ptr(), w.data_ptr(), None, None, 0, c.data_ptr(), 0, ldc, 256, N, Kd, act,
+                                           st) != 0
+    assert lib.tocvp_gemm_f16chunk_f32(a.data_ptr() + 2, w.data_ptr(), None, None, 0, c.data_ptr(), 0, 512, 256, 512, 128, 0,
+                                       st) != 0
+    torch.cuda.synchronize()

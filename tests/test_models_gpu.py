@@ -805,3 +805,48 @@ def test_textocvp_t5_against_transformers_golden_and_oracle():
         window = torch.cat([window, cur.unsqueeze(1)], dim=1)
         ref.append(cur)
     assert max_abs(got.cpu(), torch.stack(ref, dim=1)) < 1e-4
+
+
+@torch.no_grad()
+def test_config4_plane_handovers_and_chunk_gemm_are_bit_identical(monkeypatch):
+    """
+    BASELINE configs[3] at row counts that take the round-4 GEMM path: the MLPPatchDecoder (reference decoders.py:264-307)
+    and the ViT blocks (timm_encoders.py:59-70) hand LayerNorm outputs / hidden activations to their wide projections as
+    fp16 operand planes, which run the chunk-resident persistent GEMM (csrc/gemm_f16c.hip; the decoder's 769-wide head
+    zero-padded to 1024 columns).  Producer-written planes are the split the consumer would compute and the kernel keeps
+    the k order: features, masks and ViT tokens must equal the fp32 hand-over path BIT FOR BIT.
+    """
+    from textocvp_amd import kernels as K
+    from textocvp_amd.setup_model import default_dinosaur_params
+    from textocvp_amd.models.EncodersDecoders import decoders as D, timm_encoders as T
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224)).eval()
+    synth.fill_module_(model, prefix="dino.")
+    model = model.to(DEV)
+    slots = gpu(synth.synth_noise(4, 24, 128, seed=9))                     # 4 x 24 x 256 = 24576 rows
+    videos = gpu(synth.synth_videos(1, 64, height=224, width=224, seed=72))  # 64 x 257 = 16448 rows
+    names = []
+
+    class Names:
+        def wrap(self, name, units, fn):
+            names.append(name)
+            return fn()
+
+    def run(planes):
+        monkeypatch.setattr(D, "_MLP_PLANES", planes)
+        monkeypatch.setattr(T, "_VIT_PLANES", planes)
+        monkeypatch.setattr(K, "_GEMM_CHUNK", planes)
+        dec = model(mode="decode", slots=slots)
+        feats = model.encoder(videos)
+        return dec["recons_feats"], dec["masks"], dec["recons_imgs"], feats
+
+    ref = run(False)
+    K.TIMER = Names()
+    try:
+        got = run(True)
+    finally:
+        K.TIMER = None
+    assert any(n == "gemm_split22_24576x1024x1024" for n in names), names[:8]     # incl. the padded head
+    assert sum(n == "gemm_split22_24576x1024x1024" for n in names) == 3
+    assert any(n == "gemm_split22_16448x2304x768" for n in names) and any(n == "gemm_split22_16448x768x3072" for n in names)
+    for a, b, what in zip(ref, got, ("recons_feats", "masks", "recons_imgs", "vit tokens")):
+        assert torch.equal(a, b), what

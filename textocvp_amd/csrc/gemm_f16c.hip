@@ -1,7 +1,8 @@
 // Split-fp16 ("f16x3", fp32-class) GEMM with the ACTIVATION CHUNK RESIDENT IN LDS and the weights streamed from L2 in
 // MFMA-fragment order -- the loop of the fused MLP's second product (mlp_fused.hip) as a GEMM of its own:
 //
-//     C (M, N) = act(A W^T + bias) (+ R)        A as fp16 operand planes (M, 2, K) of 2^8 a, N % 512 == 0, K % 128 == 0
+//     C (M, N) = act(A W^T + bias) (+ R)        A as fp16 operand planes (M, 2, K) of 2^8 a, N % 512 == 0 or N % 384 == 0,
+//                                               K % 128 == 0
 //
 // replaces nn.Linear where both dimensions are wide (reference decoders.py:264-307 MLPPatchDecoder layers 1024 -> 1024,
 // the DINOv2 ViT projections behind timm_encoders.py:59-70, Blocks/attention.py:167-175).  The in-loop-split kernel
@@ -21,6 +22,8 @@
 //     once and served to the other column tiles by that XCD's L2).
 // Arithmetic is bit-identical to tocvp_gemm_bf16wfrag_f32 with f16x3 planes (same planes, same k order, products
 // a_hi w_lo + a_lo w_hi + a_hi w_hi per 16-deep step into one accumulator, same epilogue expressions).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -28,13 +31,10 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128;                      // tokens per workgroup
-constexpr int BN = 512;                      // outputs per workgroup
 constexpr int CK = 128;                      // k per chunk
 constexpr int AROW = 512;                    // bytes per token in a chunk image: [plane 0: 128 k | plane 1: 128 k]
 constexpr int ABYTES = BM * AROW;            // 64 KB
 constexpr float SA = TOCVP_F16X3_ACT_SCALE, SW = TOCVP_F16X3_WEIGHT_SCALE;
-constexpr int OS = BN + 4;                   // floats per staged output row (16 B pad: conflict-free stores)
-constexpr int LDS_BYTES = 64 * OS * 4 > 2 * ABYTES ? 64 * OS * 4 : 2 * ABYTES;   // 132 096
 
 struct ChunkArgs {
     const unsigned char* A;                  // (M, 2, K) fp16 planes of 2^8 a
@@ -90,25 +90,38 @@ __device__ __forceinline__ float act_of(float v, int act) {
 }
 
 // ACT / CSPLIT / HASR are compile-time: with run-time switches the write-out loop compiled into a branch ladder that
-// waits for every LDS read on its own
-template <int ACT, bool CSPLIT, bool HASR>
+// waits for every LDS read on its own.
+//
+// PERSISTENT: the grid is one workgroup per CU (a multiple of 8).  Workgroup j runs on XCD j & 7 as that XCD's slot j >> 3
+// and walks the XCD's tiles -- row tiles r = xcd (mod 8), all column tiles of a row tile consecutive -- with the stride of
+// the slot count, so the slots of an XCD work on neighbouring column tiles of the same row tiles at the same time (the A
+// chunk comes from HBM once per XCD) and every CU gets the same number of tiles by construction (dispatched one tile per
+// workgroup, 1536 equal tiles on 256 CUs ran 534 us with 6 x 151 k cycles per CU = 1.7 GHz-equivalent: some CUs took a
+// seventh tile).  The chunks of consecutive tiles form ONE stream: chunk 0 of the next tile is fetched during the last
+// chunk of this one and the weight ring runs on into the next tile's fragments, so a tile has no prologue; its epilogue
+// goes through the chunk buffer that is free at that point.
+// NT = 32-output blocks per wave: 4 (512 outputs per workgroup) or 3 (384: widths like 768 / 2304 of the ViT); a step's
+// weight fragments come in two halves, output blocks {0, 1} and {2 .. NT - 1}.
+template <int NT, int ACT, bool CSPLIT, bool HASR>
 __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    constexpr int BN = 128 * NT;                                     // outputs per workgroup (32 NT per wave)
+    constexpr int NJ1 = NT - 2;                                      // output blocks of a step's second half
+    constexpr int OROW = BN * 4;                                     // bytes per staged output row
+    constexpr int QPR = BN / 4;                                      // output quads per row
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * ABYTES];
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
     typedef const __attribute__((address_space(1))) f16x8* gv8;
 
-    // ---- tile of this workgroup: ids run over groups of 8 row tiles x all column tiles; inside a group the id's low three
-    // bits (= the XCD it is dispatched to) pick the row tile and the column tiles follow each other on that XCD
-    const int per_group = 8 * p.col_tiles;
-    const int grp = (int)blockIdx.x / per_group, rem = (int)blockIdx.x % per_group;
-    const int rt = grp * 8 + (rem & 7), ct = rem >> 3;
-    if (rt >= p.row_tiles) return;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, nslot = (int)gridDim.x >> 3;
+    const int nrows_x = p.row_tiles > xcd ? (p.row_tiles - xcd + 7) >> 3 : 0;     // row tiles of this XCD
+    const int nitems = nrows_x * p.col_tiles;
+    int item = slot;
+    if (item >= nitems) return;
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int KS = p.K / 16, nchunk = p.K / CK;
-    const int m0 = rt * BM, n0 = ct * BN;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned x15 = (unsigned)(l31 & 15);
 
@@ -116,13 +129,15 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
     // lane-linear; the conflict-free order comes from the SOURCE side: physical 16-byte chunk c of token r holds logical
     // chunk c ^ (r & 15), logical chunk = plane * 16 + k / 8
     unsigned voff_a[16];
+    auto set_voff = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = 2 * (w * 16 + i) + (lane >> 5);
-        const int lc = (lane & 31) ^ (row & 15);
-        const int grow = min(m0 + row, p.M - 1);                     // rows past M re-read the last row (never stored)
-        voff_a[i] = (unsigned)((((size_t)grow * 2 + (lc >> 4)) * p.K + (lc & 15) * 8) * 2);
-    }
+        for (int i = 0; i < 16; ++i) {
+            const int row = 2 * (w * 16 + i) + (lane >> 5);
+            const int lc = (lane & 31) ^ (row & 15);
+            const int grow = min(m0 + row, p.M - 1);                 // rows past M re-read the last row (never stored)
+            voff_a[i] = (unsigned)((((size_t)grow * 2 + (lc >> 4)) * p.K + (lc & 15) * 8) * 2);
+        }
+    };
     // (inline assembly on purpose: see mlp_fused.hip -- the compiler's wait-count pass would put vmcnt(0) in front of
     // every LDS read behind a global_load_lds builtin; the landing is guarded by the counted wait in front of the
     // chunk barrier)
@@ -139,15 +154,22 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
         }
     };
 
-    // ---- weight fragments from L2 in HALVES of 24 MFMAs: half q = output tiles 2 (q & 1), + 1 of 16-deep step q / 2
-    const int nb0 = n0 / 32 + 4 * w;
-    const int qmax = 2 * KS - 1;
+    // ---- weight fragments from L2 in HALVES of 24 MFMAs: half q of a tile = output tiles 2 (q & 1), + 1 of 16-deep step
+    // q / 2; halves past the end of the tile are the first halves of the NEXT tile (the ring never drains)
+    const int nq = 2 * KS;
+    const unsigned char* wcur;
+    const unsigned char* wnxt;
     auto load_w_half = [&](f16x8 (&b)[4], int q) {
-        q = min(q, qmax);                                            // past the end: a harmless re-load, never used
+        const unsigned char* wb = wcur;
+        if (q >= nq) {
+            q -= nq;
+            wb = wnxt;
+        }
         const int s = q >> 1, jt0 = (q & 1) * 2;
 #pragma unroll
         for (int jl = 0; jl < 2; ++jl) {
-            const unsigned char* base = p.Wf + ((size_t)(nb0 + jt0 + jl) * KS + s) * 2048;
+            if (jl >= NJ1 && (q & 1)) break;                         // NT = 3: the second half holds ONE output block
+            const unsigned char* base = wb + ((size_t)(jt0 + jl) * KS + s) * 2048;
             asm volatile("" : "+s"(base));
             const gptr g = (gptr)base + lane16;
 #pragma unroll
@@ -155,14 +177,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
         }
     };
 
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    f32x16 acc[4][NT];
     struct Frag { f16x8 v[4][2]; };                                  // token operand of one 16-deep step: [token block][plane]
     auto read_a = [&](Frag& f, unsigned buf_off, int s) {
         const unsigned char* ab = lds + buf_off + l31 * AROW;
@@ -176,17 +191,27 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jl = 0; jl < 2; ++jl) {
+            for (int jl = 0; jl < (jt0 == 0 ? 2 : NJ1); ++jl) {
                 acc[i][jt0 + jl] = mfma16(b[2 * jl + 1], f.v[i][0], acc[i][jt0 + jl]);     // act hi x w lo
                 acc[i][jt0 + jl] = mfma16(b[2 * jl + 0], f.v[i][1], acc[i][jt0 + jl]);     // act lo x w hi
                 acc[i][jt0 + jl] = mfma16(b[2 * jl + 0], f.v[i][0], acc[i][jt0 + jl]);     // act hi x w hi
             }
     };
 
+    // tile of an item of this XCD: row tile 8 (item / col_tiles) + xcd, column tile item % col_tiles
+    int m0 = ((item / p.col_tiles) * 8 + xcd) * BM, n0 = (item % p.col_tiles) * BN;
+    wcur = p.Wf + (size_t)(n0 / 32 + NT * w) * KS * 2048;
+    wnxt = wcur;
+
     f16x8 wr[4][4];                                                  // ring of weight-fragment halves, slot = half & 3
     Frag F0, F1;
     GC_STAMP(st_start);
+    set_voff(m0);
     dma_a(0, 0, 0, 16);
+    {
+        const int nx = item + nslot < nitems ? item + nslot : item;
+        wnxt = p.Wf + (size_t)((nx % p.col_tiles) * (BN / 32) + NT * w) * KS * 2048;
+    }
     load_w_half(wr[0], 0);
     load_w_half(wr[1], 1);
     load_w_half(wr[2], 2);
@@ -194,129 +219,152 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
     __syncthreads();
     read_a(F0, 0, 0);
     GC_STAMP(st_loop);
+#ifdef TOCVP_GC_STAMP
+    unsigned long long st_k = 0, st_e = 0;
+#endif
     unsigned cur = 0, oth = ABYTES;
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;
-        // entering chunk c: its image is complete in `cur`, F0 = its step-0 fragments, every wave is done with `oth`
-        // (barrier in step 7 of the previous chunk): chunk c + 1 goes there, two DMA instructions per half in steps 0 .. 3
+    for (;;) {
+        const int nitem = item + nslot;
+        const bool has_next = nitem < nitems;
+        const int nx = has_next ? nitem : item;
+        const int m0n = ((nx / p.col_tiles) * 8 + xcd) * BM, n0n = (nx % p.col_tiles) * BN;
+        wnxt = p.Wf + (size_t)(n0n / 32 + NT * w) * KS * 2048;
+        GC_STAMP(s0);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int q = 16 * c + 2 * s;
-            Frag& fc = (s & 1) ? F1 : F0;
-            Frag& fn = (s & 1) ? F0 : F1;
-            if (GABL != 2) load_w_half(wr[(q + 3) & 3], q + 3);
-            if (GABL != 1 && s < 4 && more) dma_a(oth, c + 1, 4 * s, 4 * s + 2);
-            if (s < 7) {
-                read_a(fn, cur, s + 1);
-            } else {
-                // every wave holds its step-7 fragments (the last reads of `cur`) and its share of chunk c + 1 has landed:
-                // those DMA instructions were issued in steps 0 .. 3, at least 12 weight-fragment loads ago
-                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (more) read_a(fn, oth, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+            // entering chunk c: its image is complete in `cur`, F0 = its step-0 fragments, every wave is done with `oth`
+            // (barrier in step 7 of the previous chunk): the next chunk of the stream goes there -- chunk c + 1 of this
+            // tile or chunk 0 of the next -- two DMA instructions per half in steps 0 .. 3
+            const bool lastc = c + 1 == nchunk;
+            if (lastc) set_voff(m0n);                                // this tile's rows have all been requested
+            const bool more = !lastc || has_next;
+            const int cn = lastc ? 0 : c + 1;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int q = 16 * c + 2 * s;
+                Frag& fc = (s & 1) ? F1 : F0;
+                Frag& fn = (s & 1) ? F0 : F1;
+                if (GABL != 2) load_w_half(wr[(q + 3) & 3], q + 3);
+                if (GABL != 1 && s < 4 && more) dma_a(oth, cn, 4 * s, 4 * s + 2);
+                if (s < 7) {
+                    read_a(fn, cur, s + 1);
+                } else {
+                    // every wave holds its step-7 fragments (the last reads of `cur`) and its share of the next chunk has
+                    // landed: those DMA instructions were issued in steps 0 .. 3, at least 12 weight-fragment loads ago
+                    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (!lastc) read_a(fn, oth, 0);
+                }
+                if (GABL != 4) mfma2(fc, wr[q & 3], 0);
+                if (s < 4) weave<24, 8, 6>();
+                else weave<24, 8, 4>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (GABL != 2) load_w_half(wr[(q + 4) & 3], q + 4);
+                if (GABL != 1 && s < 4 && more) dma_a(oth, cn, 4 * s + 2, 4 * s + 4);
+                if (GABL != 4) mfma2(fc, wr[(q + 1) & 3], 2);
+                if (s < 4) weave<12 * NJ1, 0, 2 * NJ1 + 2>();
+                else weave<12 * NJ1, 0, 2 * NJ1>();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (GABL != 4) mfma2(fc, wr[q & 3], 0);
-            if (s < 4) weave<24, 8, 6>();
-            else weave<24, 8, 4>();
-            __builtin_amdgcn_sched_barrier(0);
-            if (GABL != 2) load_w_half(wr[(q + 4) & 3], q + 4);
-            if (GABL != 1 && s < 4 && more) dma_a(oth, c + 1, 4 * s + 2, 4 * s + 4);
-            if (GABL != 4) mfma2(fc, wr[(q + 1) & 3], 2);
-            if (s < 4) weave<24, 0, 6>();
-            else weave<24, 0, 4>();
-            __builtin_amdgcn_sched_barrier(0);
+            const unsigned t_ = cur;
+            cur = oth;
+            oth = t_;
         }
-        const unsigned t_ = cur;
-        cur = oth;
-        oth = t_;
+        GC_STAMP(s1);
+        // here: `cur` holds chunk 0 of the next tile (landed, if there is one), `oth` -- the last chunk's image -- is free
+        // (barrier of its step 7), the ring holds halves 0 .. 2 of the next tile
+
+        // ---- epilogue.  Register quad g of acc[i][jt] = outputs n0 + 128 w + 32 jt + 8 g + 4 h .. + 3 of token 32 i + l31.
+        // Token block i (32 tokens x 512 outputs = 64 KB of raw accumulators) goes through the free chunk buffer with a
+        // 16-byte-chunk swizzle (physical chunk = logical ^ (token & 15): conflict-free both ways) and leaves as whole rows:
+        // every load of the residual and every store covers 1 KiB (fp32) / 512 B per plane of contiguous memory.  A lane
+        // writes the same four output columns in every row, so the bias is ONE quad per lane.
+        if (GABL != 5) {
+            unsigned char* const ost = lds + oth;
+            // lane -> (row parity, output quad): QPR quads per row, two rows per pass of the workgroup (NT = 3: 192 of
+            // the 256 threads write out)
+            const int lcq = t % QPR, rsel = t / QPR;
+            const bool wout = rsel < 2;
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4 * lcq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i > 0) __syncthreads();                          // the previous block has been read out
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned lc = (unsigned)(8 * NT * w + 8 * jt + 2 * g + h);
+                        const f32x4 v = {acc[i][jt][4 * g], acc[i][jt][4 * g + 1], acc[i][jt][4 * g + 2], acc[i][jt][4 * g + 3]};
+                        if (GABL != 7) *reinterpret_cast<f32x4*>(ost + l31 * OROW + ((lc ^ x15) << 4)) = v;
+                        else if (v[0] == 123.456f) ost[0] = 1;
+                    }
+                __syncthreads();
+                // 32 rows x QPR quads; a wave-instruction covers 64 lanes x 16 B of one or two rows, 8 quads in flight per lane
+                if (wout) {
+#pragma unroll 1
+                    for (int it0 = 0; it0 < 16; it0 += 8) {
+                        f32x4 rq[8], vq[8];
+                        if (HASR) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const int row = m0 + 32 * i + (rsel + 2 * (it0 + k));
+                                rq[k] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(row, p.M - 1) * p.ldr + n0 + 4 * lcq);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int rl = rsel + 2 * (it0 + k);
+                            vq[k] = f32x4{1.f, 2.f, 3.f, 4.f};
+                            if (GABL != 7)
+                                vq[k] = *reinterpret_cast<const f32x4*>(ost + rl * OROW + (((unsigned)lcq ^ (unsigned)(rl & 15)) << 4));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int rl = rsel + 2 * (it0 + k);
+                            const int row = m0 + 32 * i + rl;
+                            f32x4 v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = act_of(vq[k][u] * (1.f / (SA * SW)) + bq[u], ACT);
+                            if (HASR) v += rq[k];
+                            if (GABL == 6) {
+                                if (v[0] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
+                            } else if (row < p.M) {
+                                if (CSPLIT) tocvp_store_planes4(p.C, (size_t)row * 2 * p.N + n0 + 4 * lcq, (size_t)p.N, v, 22);
+                                else *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + n0 + 4 * lcq) = v;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][NT - 1][3] == 123.456f) {
+            static_cast<float*>(p.C)[0] = 1.f;
+        }
+        GC_STAMP(s2);
+#ifdef TOCVP_GC_STAMP
+        st_k += s1 - s0;
+        st_e += s2 - s1;
+#endif
+        if (!has_next) break;
+        item = nitem;
+        m0 = m0n;
+        n0 = n0n;
+        wcur = wnxt;
+        __syncthreads();                                             // `oth` has been read out: the stream may fill it again
+        read_a(F0, cur, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the fragment loads past the end
-    GC_STAMP(st_loop_end);
-    if (GABL == 5) {
-        if (acc[0][0][0] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
-        return;
-    }
-
-    // ---- epilogue.  Register quad g of acc[i][jt] = outputs n0 + 128 w + 32 jt + 8 g + 4 h .. + 3 of token 32 i + l31.
-    // The tile goes through LDS, 64 tokens at a time as fp32 rows of 512 + 4 floats, and leaves as whole rows: every load
-    // of the residual and every store covers 1 KiB (fp32) / 512 B per plane of contiguous memory.
-    float* const ost = reinterpret_cast<float*>(lds);
-    // the wave's 128 bias values, one round trip for all of them (a load per quad inside the staging loop compiled into
-    // sixteen serial L2 round trips per half tile: 62 k of a tile's 186 k cycles)
-    f32x4 bq[4][4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[jt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bq[jt][g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 128 * w + 32 * jt + 8 * g + 4 * h);
-    }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();                                             // LDS free: the products / the previous half are done
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = 128 * w + 32 * jt + 8 * g + 4 * h;
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    // (static accumulator indices: both halves are spelled out; the activation is applied on the way out)
-                    f32x4 v;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        v[u] = (half == 0 ? acc[ii][jt][4 * g + u] : acc[2 + ii][jt][4 * g + u]) * (1.f / (SA * SW)) + bq[jt][g][u];
-                    if (GABL != 7) *reinterpret_cast<f32x4*>(ost + (32 * ii + l31) * OS + col) = v;
-                    else if (v[0] == 123.456f) ost[0] = 1.f;
-                }
-            }
-        __syncthreads();
-        // 64 rows x 128 quads; a wave-instruction = half a row (64 lanes x 16 B), 8 residual quads in flight per lane
-#pragma unroll 1
-        for (int it0 = 0; it0 < 32; it0 += 8) {
-            f32x4 rq[8], vq[8];
-            if (HASR) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int idx = t + 256 * (it0 + k);
-                    const int row = m0 + 64 * half + (idx >> 7), c4 = (idx & 127) * 4;
-                    rq[k] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(row, p.M - 1) * p.ldr + n0 + c4);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = t + 256 * (it0 + k);
-                vq[k] = f32x4{1.f, 2.f, 3.f, 4.f};
-                if (GABL != 7) vq[k] = *reinterpret_cast<const f32x4*>(ost + (idx >> 7) * OS + (idx & 127) * 4);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = t + 256 * (it0 + k);
-                const int rl = idx >> 7, c4 = (idx & 127) * 4;
-                const int row = m0 + 64 * half + rl;
-                f32x4 v = vq[k];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = act_of(v[u], ACT);
-                if (HASR) v += rq[k];
-                if (GABL == 6) {
-                    if (v[0] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
-                } else if (row < p.M) {
-                    if (CSPLIT) tocvp_store_planes4(p.C, (size_t)row * 2 * p.N + n0 + c4, (size_t)p.N, v, 22);
-                    else *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + n0 + c4) = v;
-                }
-            }
-        }
-    }
 #ifdef TOCVP_GC_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (t == 0 && blockIdx.x < 4096) {
         unsigned long long* st = tocvp_gc_stamps + blockIdx.x * 4;
-        st[0] = st_start; st[1] = st_loop; st[2] = st_loop_end; st[3] = __builtin_amdgcn_s_memtime();
+        st[0] = st_loop - st_start; st[1] = st_k; st[2] = st_e; st[3] = __builtin_amdgcn_s_memtime() - st_start;
     }
 #endif
 }
@@ -329,10 +377,22 @@ extern "C" int tocvp_gc_read_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+static int gc_cus() {
+    static const int v = []() {
+        const char* e = getenv("TOCVP_GEMM_CHUNK_CUS");
+        int dev = 0, n = 0;
+        if (e) n = atoi(e);
+        else if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n >= 8 ? n / 8 * 8 : 8;
+    }();
+    return v;
+}
+
 extern "C" int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
                                        void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream) {
     TOCVP_CHECK_ARG(A_planes && W_frag && C && M >= 0 && N > 0 && K > 0);
-    TOCVP_CHECK_ARG((N % BN) == 0 && (K % CK) == 0);
+    TOCVP_CHECK_ARG(((N % 512) == 0 || (N % 384) == 0) && (K % CK) == 0);
     TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
     TOCVP_CHECK_ARG(c_split || (ldc >= N && (ldc & 3) == 0));
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0));
@@ -341,14 +401,20 @@ extern "C" int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag,
         (R && !tocvp_aligned16(R)))
         return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
-    const int row_tiles = (M + BM - 1) / BM, col_tiles = N / BN;
+    const int bn = (N % 512) == 0 ? 512 : 384;
+    const int row_tiles = (M + BM - 1) / BM, col_tiles = N / bn;
     ChunkArgs p{static_cast<const unsigned char*>(A_planes), static_cast<const unsigned char*>(W_frag), bias, R, ldr, C, ldc,
                 c_split, M, N, K, act, row_tiles, col_tiles};
-    const long groups = (row_tiles + 7) / 8;
-    TOCVP_CHECK_ARG(groups * 8 * col_tiles < 0x7fffffffL);
-    const dim3 grid((unsigned)(groups * 8 * col_tiles));
+    // one workgroup per CU (a multiple of 8: the kernel takes id & 7 as its XCD), fewer when there are fewer tiles
+    const int per_xcd = ((row_tiles + 7) / 8) * col_tiles;              // most tiles any XCD holds
+    const int slots = per_xcd < gc_cus() / 8 ? per_xcd : gc_cus() / 8;
+    const dim3 grid((unsigned)(8 * slots));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define GC_LAUNCH(A_, S_, R_) hipLaunchKernelGGL((gemm_f16x3_chunk_kernel<A_, S_, R_>), grid, dim3(256), 0, st, p)
+#define GC_LAUNCH(A_, S_, R_)                                                                                   \
+    do {                                                                                                        \
+        if (bn == 512) hipLaunchKernelGGL((gemm_f16x3_chunk_kernel<4, A_, S_, R_>), grid, dim3(256), 0, st, p);  \
+        else hipLaunchKernelGGL((gemm_f16x3_chunk_kernel<3, A_, S_, R_>), grid, dim3(256), 0, st, p);           \
+    } while (0)
 #define GC_LAUNCH_SR(A_)                                  \
     do {                                                  \
         if (c_split) {                                    \

@@ -446,10 +446,11 @@ _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment o
 # default plane inputs go to the two-workgroups-per-CU planes kernel of gemm_bf16.hip (gemm_f16_planes_kernel; small
 # shapes: the in-loop kernel's ASPLIT form), which shares a CU with the decoder's workgroups
 _GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
-# chunk-resident f16x3 GEMM (gemm_f16c.hip) for plane inputs with N % 512 == 0, K % 128 == 0 (TOCVP_GEMM_CHUNK=0: off)
-_GEMM_CHUNK = os.environ.get("TOCVP_GEMM_CHUNK", "0") != "0"
-_GEMM_CHUNK_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_ROWS", "16384"))
-_GEMM_CHUNK_MIN_K = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_K", "512"))
+# chunk-resident persistent f16x3 GEMM (gemm_f16c.hip) for plane inputs with N % 512 == 0, K % 128 == 0, from
+# _GEMM_CHUNK_MIN_TILES tiles of 128 x 512 up (one workgroup per CU: fewer tiles leave CUs idle and the 64 x 64 / 128 x 128
+# kernels win; 9600 x 512 x 2048 = 75 tiles: 118 vs 103 us, 9600 x 1536 x 512 = 225 tiles: 55 vs 63 us).  TOCVP_GEMM_CHUNK=0: off
+_GEMM_CHUNK = os.environ.get("TOCVP_GEMM_CHUNK", "1") != "0"
+_GEMM_CHUNK_MIN_TILES = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_TILES", "192"))
 _GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
@@ -714,11 +715,13 @@ def mlp_fused(x, w1, b1, w2, b2, residual=None):
 # --------------------------------------------------------------------------------------------
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_div=1, rv_flip=False,
-           out=None, precision=None, out_split=0):
+           out=None, precision=None, out_split=0, chunk_ok=True):
     """
     y = act(x W^T + bias + rowvec[idx(row)]) + residual over the last axis of ``x``.
     x: (..., K) contiguous fp32 tensor or a SplitAct; weight: (N, K) in nn.Linear layout.
     out_split = 2 / 3 / 22: return a SplitAct (operand planes) for a following split GEMM.
+    chunk_ok = False keeps a plane-input product off the persistent chunk-resident kernel (one workgroup per CU with 128 KB
+    of LDS: it cannot share a CU with another stream's workgroups -- the predictor under the overlapped decoder).
     """
     _dev_f32(weight, "weight")
     N, K = weight.shape
@@ -759,14 +762,19 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
         if not pre_split:
             _check_f16_range(absmax(x2), f"f16x3 GEMM ({M}x{N}x{K}) activation")
         _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
-    if (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and rowvec is None and N % 512 == 0 and K % 128 == 0 and
-            M >= _GEMM_CHUNK_MIN_ROWS and K >= _GEMM_CHUNK_MIN_K and M * 4 * K < 2 ** 32 and act in (ACT_NONE, ACT_RELU, ACT_GELU)):
-        # A chunks resident in LDS, weights streamed in fragment order (gemm_f16c.hip)
+    bn = 512 if N % 512 == 0 else 384
+    if (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and chunk_ok and rowvec is None and N % bn == 0 and K % 128 == 0 and
+            ((M + 127) // 128) * (N // bn) >= _GEMM_CHUNK_MIN_TILES and act in (ACT_NONE, ACT_RELU, ACT_GELU)):
+        # A chunks resident in LDS, weights streamed in fragment order (gemm_f16c.hip); 32-bit DMA offsets: row blocks
         ws = _split_weight(w, 22, frag=True)
-        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
-            lib().tocvp_gemm_f16chunk_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
-                                          int(bool(out_split)), N, M, N, K, int(act), _stream()),
-            "tocvp_gemm_f16chunk_f32"))
+        step = ((2 ** 32 - 1) // (4 * K)) // 128 * 128
+        for r0 in range(0, M, step):
+            mb = min(step, M - r0)
+            _timed(lambda: f"gemm_split{nsplit}_{mb}x{N}x{K}", 2.0 * mb * N * K, lambda: _check(
+                lib().tocvp_gemm_f16chunk_f32(x2[r0:].data_ptr(), _ptr(ws), _ptr(bias),
+                                              None if r2 is None else r2[r0:].data_ptr(), N, out[r0:].data_ptr(),
+                                              int(bool(out_split)), N, mb, N, K, int(act), _stream()),
+                "tocvp_gemm_f16chunk_f32"))
     elif (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
             M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
         # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)

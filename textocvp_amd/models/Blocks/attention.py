@@ -47,6 +47,11 @@ _PRESPLIT_MLP = os.environ.get("TOCVP_PRESPLIT_MLP", "1") != "0"
 _PRESPLIT_MIN_N = 1536
 # B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster (round 3, two GEMMs per MLP)
 _PRESPLIT_MIN_ROWS = int(os.environ.get("TOCVP_PRESPLIT_MIN_ROWS", "16384"))
+# the persistent chunk-resident GEMM (csrc/gemm_f16c.hip) for the predictor's plane-input products: 189 vs 222 us isolated on
+# the qkv projection at 38400 rows, but its workgroups need a whole CU each and stall the decoder's on the other stream:
+# A/B at B = 128 on one box 3997 / 4002 (on) vs 4026 / 4027 frames/s (off) with the decode overlapped, 3894 / 3888 vs
+# 3868 / 3872 without -- off by default
+_CHUNK_GEMM = os.environ.get("TOCVP_PREDICTOR_CHUNK_GEMM", "0") != "0"
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
 # LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
 _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
@@ -110,8 +115,8 @@ def _mlp(x, seq, residual):
         # the predictor's 512 -> 2048 -> 512 pairs at many rows: ONE kernel, the hidden activation stays on the CU
         # (csrc/mlp_fused.hip; bit-identical to the two GEMMs below on whole 128-row tiles)
         return K.mlp_fused(x, w1, b1, w2, b2, residual=residual)
-    h = K.linear(x, w1, b1, act=K.ACT_RELU, out_split=ns)
-    return K.linear(h, w2, b2, residual=residual)
+    h = K.linear(x, w1, b1, act=K.ACT_RELU, out_split=ns, chunk_ok=_CHUNK_GEMM)
+    return K.linear(h, w2, b2, residual=residual, chunk_ok=_CHUNK_GEMM)
 
 
 SD_PLANES = 128          # slot dim of the plane-input slot-attention kernel
@@ -272,7 +277,7 @@ class MultiHeadSelfAttention(MetaAttention):
         wq, wk, wv, wo, heads = _params(self, lambda m: (m.q.weight, m.k.weight, m.v.weight, m.out_projection[0].weight,
                                                           m.num_heads))
         w = self._derived.get("w_qkv", [wq, wk, wv], lambda: torch.cat([wq, wk, wv], 0).contiguous())
-        qkv = K.linear(x, w)                                              # (B, T, 3E)
+        qkv = K.linear(x, w, chunk_ok=_CHUNK_GEMM)                        # (B, T, 3E)
         o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, (E // heads) ** -0.5,
                   out_split=_ns(E, n_out=wo.shape[0]))
         return K.linear(o, wo, residual=residual)
@@ -288,7 +293,7 @@ class MultiHeadSelfAttention(MetaAttention):
         B, T, E = x.shape
         w_kv = self._derived.get("w_kv", [self.k.weight, self.v.weight],
                                  lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
-        kv = K.linear(x, w_kv)                                            # (B, T, 2E)
+        kv = K.linear(x, w_kv, chunk_ok=_CHUNK_GEMM)                      # (B, T, 2E)
         q = K.linear(K.contiguous(x[:, T - n_last:]), self.q.weight)      # (B, n_last, E)
         o = K.mha(q, kv[..., :E], kv[..., E:], self.num_heads, (E // self.num_heads) ** -0.5)
         return K.linear(o, self.out_projection[0].weight, residual=residual_last)

@@ -14,8 +14,9 @@ from ..Blocks.model_blocks import ConvBlock
 from ..Blocks.model_utils import Derived
 
 # MLPPatchDecoder: hidden activations between its Linear layers as producer-written fp16 operand planes
-# (TOCVP_DINO_MLP_PLANES=0 restores the fp32 hand-over); the all-DMA planes GEMM takes them when TOCVP_GEMM_P2 is on
-_MLP_PLANES = os.environ.get("TOCVP_DINO_MLP_PLANES", "0") != "0"
+# (TOCVP_DINO_MLP_PLANES=0 restores the fp32 hand-over): the 1024 -> 1024 layers then run the chunk-resident GEMM
+# (gemm_f16c.hip), bit-identical to the fp32 hand-over
+_MLP_PLANES = os.environ.get("TOCVP_DINO_MLP_PLANES", "1") != "0"
 _MLP_PLANES_MIN_ROWS = int(os.environ.get("TOCVP_DINO_MLP_PLANES_MIN_ROWS", "16384"))
 
 __all__ = ["get_decoder", "ConvDecoder", "MLPPatchDecoder"]
@@ -225,10 +226,10 @@ class ConvDecoder(nn.Module):
             "provided: use SAVi.decode / decode_slots (the broadcast tensor never exists here)")
 
 
-def _pad_rows32(weight, bias):
-    """ (N, K) weight / (N,) bias zero-padded to the next multiple of 32 output features """
+def _pad_rows32(weight, bias, mult=32):
+    """ (N, K) weight / (N,) bias zero-padded to the next multiple of ``mult`` output features """
     n = weight.shape[0]
-    npad = (n + 31) // 32 * 32
+    npad = (n + mult - 1) // mult * mult
     w = torch.zeros((npad, weight.shape[1]), device=weight.device, dtype=weight.dtype)
     w[:n] = weight.detach()
     b = torch.zeros((npad,), device=weight.device, dtype=weight.dtype)
@@ -342,30 +343,30 @@ class MLPPatchDecoder(nn.Module):
         N = self.num_patches
         x = slots.reshape(B * Ks, 1, D).expand(B * Ks, N, D).contiguous()  # broadcast (data movement)
         pos = self.pos_embed.detach().reshape(N, D)
-        i = 0
-        if self.initial_layer_norm:
-            ln = self.mlp[0]
-            x = K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=pos)
-            i = 1
-        else:
+        if not self.initial_layer_norm:
             raise NotImplementedError("MLPPatchDecoder without initial_layer_norm (unused by the configs)")
-        linears = [m for m in self.mlp[i:] if isinstance(m, nn.Linear)]
+        ln = self.mlp[0]
+        linears = [m for m in self.mlp[1:] if isinstance(m, nn.Linear)]
         # 37 GFLOP per frame at config 4: f16x3 split operands (fp32-class) for the layers whose
         # shapes fit the fragment-order kernel; the 769-wide head stays on the exact fp32 MFMA
         with K.gemm_precision(self.mlp_precision, owner=(self, "mlp_precision")):
             # hidden activations handed from layer to layer as fp16 operand planes written by the producing
-            # epilogue (the split the consumer would compute while staging: bit-identical); the checked pass
+            # kernel (the split the consumer would compute while staging: bit-identical); the checked pass
             # keeps fp32 hand-overs so that every activation is verified by its consumer
             planes = (_MLP_PLANES and K.active_nsplit() == 22 and not K._CHECK_RANGE and
-                      x.numel() // x.shape[-1] >= _MLP_PLANES_MIN_ROWS and
+                      B * Ks * N >= _MLP_PLANES_MIN_ROWS and D % 64 == 0 and
                       all(l.weight.shape[0] % 32 == 0 and l.weight.shape[1] % 64 == 0 for l in linears[:-1]))
+            x = K.layer_norm(x, ln.weight, ln.bias, ln.eps, add=pos, split=22 if planes else 0)
             for j, lin in enumerate(linears[:-1]):
                 x = K.linear(x, lin.weight, lin.bias, act=K.ACT_RELU, out_split=22 if planes else 0)
             # the head is out_dim = F + 1 wide (769): zero-padded to a multiple of 32 so that it runs
             # the split kernel too; the compositing kernel skips the padding columns
+            # (with plane hand-overs the padding goes to a multiple of 512 instead: the chunk-resident GEMM on 1024 columns
+            # is faster than the 64 x 64-tiled one on 800 -- 497 vs 632 us per 98304 rows)
             head = linears[-1]
-            wpad, bpad = self._derived.get("head_pad", [head.weight, head.bias],
-                                           lambda: _pad_rows32(head.weight, head.bias))
+            mult = 512 if planes and K._GEMM_CHUNK and head.weight.shape[1] % 128 == 0 else 32
+            wpad, bpad = self._derived.get(("head_pad", mult), [head.weight, head.bias],
+                                           lambda: _pad_rows32(head.weight, head.bias, mult))
             x = K.linear(x, wpad, bpad)
         recons_feats, masks = K.slot_composite(x.reshape(B, Ks, N, wpad.shape[0]),
                                                feat_dim=self.out_dim - 1)

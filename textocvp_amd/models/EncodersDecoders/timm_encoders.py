@@ -20,12 +20,18 @@ LayerNorm -> f16x3 GEMM (fused qkv, bias) -> fused attention kernel -> f16x3 GEM
 -> LayerNorm -> f16x3 GEMM (+ GELU epilogue) -> f16x3 GEMM (+ residual epilogue): 43.6 GFLOP per frame.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
 from ... import kernels as K
 from ...precision import knob
 from ..Blocks.model_utils import Derived
+
+# LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs as fp16 operand planes (TOCVP_VIT_PLANES=0: fp32 tensors)
+_VIT_PLANES = os.environ.get("TOCVP_VIT_PLANES", "1") != "0"
+_VIT_PLANES_MIN_ROWS = int(os.environ.get("TOCVP_VIT_PLANES_MIN_ROWS", "16384"))
 
 __all__ = ["ViTEncoder", "VisionTransformer", "vit_base_patch14_dinov2", "vit_small_patch14_dinov2",
            "IMAGENET_DEFAULT_MEAN"]
@@ -182,15 +188,22 @@ class ViTEncoder(nn.Module):
             patches = K.linear(cols, wp, bp, rowvec=pos_rows, rv_div=1)            # + pos_embed[1 + (row % N)]
             x[:, 0] = cls_row
             x[:, 1:] = patches.reshape(n, N, E)
+            # the LayerNorm outputs and the MLP's hidden activation go to the wide projections (qkv, fc1, fc2) as fp16
+            # operand planes written by their producers (the split the consumer would compute while staging:
+            # bit-identical), which puts those products on the chunk-resident GEMM (csrc/gemm_f16c.hip); the checked
+            # pass keeps fp32 hand-overs so that every activation is verified by its consumer
+            ns = 22 if (_VIT_PLANES and K.active_nsplit() == 22 and not K._CHECK_RANGE and E % 128 == 0 and
+                        n * (N + 1) >= _VIT_PLANES_MIN_ROWS) else 0
             for i, blk in enumerate(vb.blocks):
-                y = K.layer_norm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+                y = K.layer_norm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, split=ns)
                 qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
                 a = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], blk.attn.num_heads,
                           (E // blk.attn.num_heads) ** -0.5)
                 w, b = self._scaled(("proj", i), blk.attn.proj, blk.ls1)
                 x = K.linear(a, w, b, residual=x)
-                y = K.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-                y = K.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=K.ACT_GELU)
+                y = K.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, split=ns)
+                y = K.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=K.ACT_GELU,
+                             out_split=ns if blk.mlp.fc1.weight.shape[0] % 64 == 0 else 0)
                 w, b = self._scaled(("fc2", i), blk.mlp.fc2, blk.ls2)
                 x = K.linear(y, w, b, residual=x)
         return x[:, 1:].contiguous()                                               # class token removed (:69)
