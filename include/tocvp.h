@@ -458,6 +458,17 @@ int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale, const
 int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
                       float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                       void* stream);
+/* "Upsample(scale_factor=2) -> Conv2d(k3, p1)" of the image head (models/EncodersDecoders/decoders.py:325-365, the
+ * Upsample of Blocks/model_blocks.py:23-45 in front of the next ConvBlock) as four 2x2 convolutions over the SOURCE image,
+ * one per output phase (2 y + a, 2 x + b): the 3x3 taps that read the same source pixel are summed beforehand -- 16 tap
+ * products per source pixel instead of 36 (2.25x fewer FLOPs), same result up to the fp32 rounding of the tap sums;
+ * f16x3 arithmetic and scale / shift / ReLU epilogue of tocvp_conv3x3_f16x3_f32.
+ *   x (nimg, SH, SW, Cin) NHWC; wphase (4 phases = 2 a + b, 4 taps = 2 i + j, Cout, Cin): tap (i, j) of phase (a, b)
+ *   reads source pixel (y + i + a - 1, x + j + b - 1) and holds the sum of w[:, :, dy, dx] over dy in rows(a, i),
+ *   dx in rows(b, j), rows(0, 0) = {0}, rows(0, 1) = {1, 2}, rows(1, 0) = {0, 1}, rows(1, 1) = {2};
+ *   y (nimg, 2 SH, 2 SW, Cout).  Cin % 32 == 0, Cout % 32 == 0, SH % 8 == 0. */
+int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, const float* scale, const float* shift,
+                                float* y, int nimg, int SH, int SW, int Cin, int Cout, int relu, void* stream);
 /* generic 5x5 convolution (pad 2, + bias, optional ReLU; Cin % 32 == 0, Cout % 32 == 0, H % 8 == 0) with
  * the same f16x3 split operands: SAVi encoder convs 32 -> 32 (encoders.py:99-159).  wp: (25, Cout, Cin)
  * from tocvp_pack_conv_weights_f32. */

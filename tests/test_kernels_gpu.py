@@ -1006,3 +1006,35 @@ def test_gemm_chunk_resident_rejects_bad_arguments():
     assert lib.tocvp_gemm_f16chunk_f32(a.data_ptr() + 2, w.data_ptr(), None, None, 0, c.data_ptr(), 0, 512, 256, 512, 128, 0,
                                        st) != 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Cin,Cout,S,n,relu", [(128, 64, 16, 3, True), (64, 128, 8, 2, True), (128, 32, 40, 2, False)])
+def test_conv3x3_up2_phases_equal_the_conv_over_the_upsampled_image(Cin, Cout, S, n, relu):
+    """
+    tocvp_conv3x3_up2_f16x3_f32: "Upsample(scale_factor=2) -> Conv2d(k3, p1)" of the DINOSAUR image head (reference
+    decoders.py:325-365 with the Upsample of model_blocks.py:23-45) as four 2x2 phase convolutions over the SOURCE image
+    (the 3x3 taps that read the same source pixel summed beforehand: 2.25x fewer FLOPs).  Against float64
+    F.interpolate(nearest) + conv2d + scale / shift (+ ReLU), at the accuracy of the 3x3 kernel with the upsampling fused
+    into its loader; every output pixel of every phase is written (borders included: the zero padding carries over).
+    """
+    k = _k()
+    x = rnd("u2x", (n, S, S, Cin), "normal")
+    w = rnd("u2w", (Cout, Cin, 3, 3), "uniform", (9 * Cin) ** -0.5)
+    sc, sf = 1.0 + 0.2 * rnd("u2sc", (Cout,), "uniform", 1.0), rnd("u2sf", (Cout,), "uniform", 0.3)
+    xd, wd, scd, sfd = x.to(DEV), w.to(DEV), sc.to(DEV), sf.to(DEV)
+    y = torch.full((1,), float("nan"))
+    got = k.conv3x3_up2(xd, k.pack_conv3x3_up2_weights(wd), scd, sfd, relu=relu)
+    old = k.conv3x3(xd, k.pack_conv_weights(wd), scd, sfd, relu=relu, upsample2=True, precision="f16x3")
+    assert got.shape == (n, 2 * S, 2 * S, Cout) and bool(torch.isfinite(got).all())
+    up = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(up, w.double(), padding=1) * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    err, err_old = (got.cpu().double() - ref).abs().max().item(), (old.cpu().double() - ref).abs().max().item()
+    print(f"conv3x3_up2 {Cin}->{Cout} @ {S}: {err:.2e} vs float64 (3x3 over the upsampled image {err_old:.2e}), max |y| {ref.abs().max().item():.2f}")
+    assert err < max(2.0 * err_old, 2e-6 * max(1.0, ref.abs().max().item()))
+    # no scale (the final RGB conv): scale = NULL means 1
+    got1 = k.conv3x3_up2(xd, k.pack_conv3x3_up2_weights(wd), None, sfd, relu=False)
+    ref1 = (torch.nn.functional.conv2d(up, w.double(), padding=1) + sf.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    assert (got1.cpu().double() - ref1).abs().max().item() < 2e-6 * max(1.0, ref1.abs().max().item())

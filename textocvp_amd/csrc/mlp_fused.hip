@@ -86,6 +86,10 @@ constexpr int MABL = TOCVP_MLP_ABLATE;
 #ifndef TOCVP_MLP_DEPHASE
 #define TOCVP_MLP_DEPHASE 1
 #endif
+#ifndef TOCVP_MLP_SB1
+#define TOCVP_MLP_SB1 1
+#endif
+constexpr bool SB1 = TOCVP_MLP_SB1 != 0;      // first product's bias through the scalar cache
 constexpr int DSPLIT = TOCVP_MLP_DSPLIT;     // LDS-DMA instructions of a k-tile issued in the step behind the barrier; the rest one step later
 constexpr bool DEPHASE = TOCVP_MLP_DEPHASE != 0;
 // vmcnt in front of a k-tile's barrier = vector-memory instructions younger than the last DMA instruction of k-tile kt + 1:
@@ -264,11 +268,27 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     };
     // epilogue of the first product: bias + ReLU + fp16 planes of 2^8 h (the expressions of the GEMM epilogue and of
     // tocvp_store_planes4) -> h image.  Register quad g of acc1[i] = hidden 32 w + 8 g + 4 h .. + 3 of token 32 i + l31
+    // (the chunk's 32 bias values of this wave are wave-uniform: they arrive through the SCALAR cache, requested at the top
+    // of the chunk -- as vector loads inside this epilogue they cost three exposed L2 round trips per chunk, each behind a
+    // vmcnt(0) that also drained the weight ring)
+    typedef const __attribute__((address_space(4))) float* cfptr;
+    float sb1[32];
+    auto load_b1 = [&](int c) {
+        const cfptr b = (cfptr)(p.b1 + c * HC + 32 * w);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sb1[j] = b[j];
+    };
     auto epilogue1 = [&](int c) {
         const float* b1c = p.b1 + c * HC + 32 * w + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1c + 8 * g) * SA;      // 2^8 b (exact)
+            f32x4 bq;
+            if (SB1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = (h ? sb1[8 * g + 4 + u] : sb1[8 * g + u]) * SA;      // 2^8 b (exact)
+            } else {
+                bq = *reinterpret_cast<const f32x4*>(b1c + 8 * g) * SA;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f16x4 hi, lo;
@@ -315,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     for (int c = c_begin; c < c_end; ++c) {
         const bool last = c + 1 == c_end;                            // no look-ahead past the end of this workgroup's range
         MLP_STAMP(s0);
+        if (SB1) load_b1(c);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -463,8 +484,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     // stored as it stands, a wave-instruction would touch 32 rows x 32 bytes.  The tile goes through LDS instead (all of
     // it is free now), 64 tokens at a time as fp32 rows of 512 + 4 floats, and leaves as whole rows: every load of the
     // residual and every store covers 1 KiB of contiguous memory.
+    // The rows are staged as RAW accumulators; scale and bias are applied on the way out, where a lane writes the same
+    // four output columns in every row: ONE bias quad per lane (sixteen bias loads inside the staging loop compiled into
+    // sixteen serial L2 round trips per half tile).
     constexpr int OS = ME + 4;                                       // floats per staged row (16 B pad: conflict-free stores)
     float* const ost = reinterpret_cast<float*>(lds);
+    const f32x4 bq2 = *reinterpret_cast<const f32x4*>(p.b2 + (t & 127) * 4);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();                                             // LDS free: the products / the previous half are done
@@ -473,14 +498,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = 128 * w + 32 * jt + 8 * g + 4 * h;
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(p.b2 + col);
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
                     // (static accumulator indices: both halves are spelled out)
                     f32x4 v;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        v[u] = (half == 0 ? acc2[ii][jt][4 * g + u] : acc2[2 + ii][jt][4 * g + u]) * (1.f / (SA * SW)) + bq[u];
+                    for (int u = 0; u < 4; ++u) v[u] = half == 0 ? acc2[ii][jt][4 * g + u] : acc2[2 + ii][jt][4 * g + u];
                     *reinterpret_cast<f32x4*>(ost + (32 * ii + l31) * OS + col) = v;
                 }
             }
@@ -501,6 +524,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
                 const int rl = idx >> 7, c4 = (idx & 127) * 4;
                 const int row = m0 + 64 * half + rl;
                 f32x4 v = *reinterpret_cast<const f32x4*>(ost + rl * OS + c4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = v[u] * (1.f / (SA * SW)) + bq2[u];
                 if (HASR) v += rq[k];
                 if (row < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)row * p.ldy + c4) = v;
             }

@@ -81,6 +81,9 @@ _SIGNATURES = {
     "tocvp_gemm_f16chunk_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv3x3_up2_f16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -1405,6 +1408,42 @@ def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
     fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
     _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
               int(bool(upsample2)), _stream()), "tocvp_conv3x3_" + precision)
+    return y
+
+
+def pack_conv3x3_up2_weights(weight):
+    """
+    (Cout, Cin, 3, 3) -> (4 phases, 4 taps, Cout, Cin) for conv3x3_up2: phase (a, b) = output pixel (2 y + a, 2 x + b) of
+    "nearest x2 -> 3x3 conv"; its tap (i, j) reads source pixel (y + i + a - 1, x + j + b - 1) and holds the sum of the
+    3x3 taps that fall on that pixel (summed in float64, rounded once).
+    """
+    rows = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    w = weight.detach().double()
+    out = torch.empty((4, 4) + tuple(w.shape[:2]), device=w.device, dtype=torch.float64)
+    for a in range(2):
+        for b in range(2):
+            for i in range(2):
+                for j in range(2):
+                    out[2 * a + b, 2 * i + j] = sum(w[:, :, dy, dx] for dy in rows[(a, i)] for dx in rows[(b, j)])
+    return out.float().contiguous()
+
+
+def conv3x3_up2(x, wphase, scale, shift, relu=True):
+    """
+    NHWC (n, SH, SW, Cin) -> (n, 2 SH, 2 SW, Cout): nearest x2 upsampling + 3x3 conv (pad 1) + per-channel scale / shift
+    (+ ReLU) as four 2x2 phase convolutions over the source image (f16x3 arithmetic; tocvp_conv3x3_up2_f16x3_f32);
+    wphase from pack_conv3x3_up2_weights.
+    """
+    n, SH, SW, Cin = x.shape
+    Cout = wphase.shape[2]
+    assert x.is_contiguous() and wphase.is_contiguous() and tuple(wphase.shape[:2]) == (4, 4) and wphase.shape[3] == Cin
+    y = torch.empty((n, 2 * SH, 2 * SW, Cout), device=x.device, dtype=torch.float32)
+    if _CHECK_RANGE:
+        _check_f16_range(absmax(x), "conv3x3_up2 (f16x3) input")
+        _check_f16_weight_range(wphase, "conv3x3_up2 (f16x3)")
+    _timed(lambda: f"conv3x3_up2_{n}x{SH}x{SW}x{Cin}x{Cout}", 2.0 * n * SH * SW * 16 * Cin * Cout, lambda: _check(
+        lib().tocvp_conv3x3_up2_f16x3_f32(_ptr(x), _ptr(wphase), _ptr(scale), _ptr(shift), _ptr(y), n, SH, SW, Cin, Cout,
+                                          int(bool(relu)), _stream()), "tocvp_conv3x3_up2_f16x3_f32"))
     return y
 
 

@@ -18,6 +18,9 @@ from ..Blocks.model_utils import Derived
 # (gemm_f16c.hip), bit-identical to the fp32 hand-over
 _MLP_PLANES = os.environ.get("TOCVP_DINO_MLP_PLANES", "1") != "0"
 _MLP_PLANES_MIN_ROWS = int(os.environ.get("TOCVP_DINO_MLP_PLANES_MIN_ROWS", "16384"))
+# image head: "Upsample(x2) -> Conv3x3" as four 2x2 phase convolutions (TOCVP_DINO_UP2_PHASES=0: 3x3 conv with the
+# upsampling fused into its tile loader, round 1)
+_UP2_PHASES = os.environ.get("TOCVP_DINO_UP2_PHASES", "1") != "0"
 
 __all__ = ["get_decoder", "ConvDecoder", "MLPPatchDecoder"]
 
@@ -313,6 +316,9 @@ class MLPPatchDecoder(nn.Module):
         x = feats.reshape(B, g, g, feats.shape[-1]).contiguous()           # NHWC feature grid
         blocks = [m for m in self.conv_patch_decoder if isinstance(m, ConvBlock)]
         up_next = False
+        # "Upsample(x2) -> Conv3x3" as four 2x2 phase convolutions over the source image (2.25x fewer FLOPs, same result up
+        # to the fp32 rounding of the summed taps; f16x3 arithmetic only)
+        phases = _UP2_PHASES and self.conv_precision == "f16x3"
         for blk, up in zip(blocks, self._upsample_after):
             conv = blk.conv
             wp = self._derived.get(("wp", id(blk)), [conv.weight],
@@ -321,7 +327,11 @@ class MLPPatchDecoder(nn.Module):
                 ("ss", id(blk)), [conv.bias] + [t for t in blk.block[1].state_dict().values()
                                                 if t.is_floating_point()],
                 lambda b=blk: b.folded_scale_shift())
-            x = K.conv3x3(x, wp, sc, sf, relu=True, upsample2=up_next, precision=self.conv_precision)
+            if up_next and phases:
+                wph = self._derived.get(("wph", id(blk)), [conv.weight], lambda c=conv: K.pack_conv3x3_up2_weights(c.weight))
+                x = K.conv3x3_up2(x, wph, sc, sf, relu=True)
+            else:
+                x = K.conv3x3(x, wp, sc, sf, relu=True, upsample2=up_next, precision=self.conv_precision)
             up_next = up
         final = self.conv_patch_decoder[-1]
 
@@ -332,8 +342,16 @@ class MLPPatchDecoder(nn.Module):
             b[:3] = final.bias
             return K.pack_conv_weights(w), b
         wp, bias = self._derived.get("final", [final.weight, final.bias], pack_final)
-        x = K.conv3x3(x, wp, None, bias, relu=False, upsample2=up_next,     # (B, S', S', 32), 3 used
-                      precision=self.conv_precision)
+        if up_next and phases:
+            def pack_final_up2():
+                w = torch.zeros((32,) + tuple(final.weight.shape[1:]), device=final.weight.device)
+                w[:3] = final.weight
+                return K.pack_conv3x3_up2_weights(w)
+            wph = self._derived.get("final_up2", [final.weight], pack_final_up2)
+            x = K.conv3x3_up2(x, wph, None, bias, relu=False)                   # (B, S', S', 32), 3 used
+        else:
+            x = K.conv3x3(x, wp, None, bias, relu=False, upsample2=up_next,     # (B, S', S', 32), 3 used
+                          precision=self.conv_precision)
         S = self.image_size
         return K.bilinear_resize_nhwc_to_nchw(x, 3, S, S)                  # also the NHWC->NCHW step
 
