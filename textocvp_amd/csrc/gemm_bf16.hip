@@ -62,6 +62,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// compile-time forms for the staged epilogues: with the run-time `act` inside their unrolled loops every staged element
+// carried a ladder of scalar branches (and the inlined erff of the GELU it did not take)
+template <int ACT> __device__ __forceinline__ float apply_act_c(float v) {
+    if constexpr (ACT == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
+    else if constexpr (ACT == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    else return v;
+}
+template <int ACT> __device__ __forceinline__ f32x4 with_r4_c(f32x4 v, f32x4 r) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ACT == TOCVP_ACT_GATE ? (r[u] > 0.f ? v[u] : 0.f) : v[u] + r[u];
+    return v;
+}
+// run `f(std::integral_constant<int, act>)` for the run-time activation code
+template <class F> __device__ __forceinline__ void dispatch_act(int act, F&& f) {
+    if (act == TOCVP_ACT_RELU) f(std::integral_constant<int, TOCVP_ACT_RELU>{});
+    else if (act == TOCVP_ACT_GELU) f(std::integral_constant<int, TOCVP_ACT_GELU>{});
+    else if (act == TOCVP_ACT_GATE) f(std::integral_constant<int, TOCVP_ACT_GATE>{});
+    else f(std::integral_constant<int, TOCVP_ACT_NONE>{});
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -524,34 +544,41 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
     if (STAGE_FITS && !p.rowvec) {
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SS);
         constexpr int F4R = WN / 4;                                   // float4 per staged row
+        float bvj[NI];                                                // one load per column block (not per row block)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = n0 + wn * WN + j * 32 + l31;
-                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[acc_row(r, h) * SS + j * 32 + l31] =
-                        apply_act(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bv, p.act);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < (32 * F4R) / 64; ++it) {
-                const int idx = lane + 64 * it;
-                const int rr = idx / F4R, c4 = (idx % F4R) * 4;
-                const int row = m0 + wm * WM + i * 32 + rr, col = n0 + wn * WN + c4;
-                if (row < p.M && col < p.N) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
-                    if (p.R) v = with_r4(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col), p.act);
-                    if (p.c_split)      // operand planes for the next split GEMM: (M, NS, N)
-                        tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, F16 ? 22 : NS);
-                    else
-                        *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            bvj[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
         }
+        dispatch_act(p.act, [&](auto AC) {
+            constexpr int ACT = decltype(AC)::value;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[acc_row(r, h) * SS + j * 32 + l31] =
+                            apply_act_c<ACT>(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bvj[j]);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < (32 * F4R) / 64; ++it) {
+                    const int idx = lane + 64 * it;
+                    const int rr = idx / F4R, c4 = (idx % F4R) * 4;
+                    const int row = m0 + wm * WM + i * 32 + rr, col = n0 + wn * WN + c4;
+                    if (row < p.M && col < p.N) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * SS + c4);
+                        if (p.R) v = with_r4_c<ACT>(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col));
+                        if (p.c_split)      // operand planes for the next split GEMM: (M, NS, N)
+                            tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, F16 ? 22 : NS);
+                        else
+                            *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        });
         return;
     }
 
@@ -715,34 +742,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_planes_kernel(GemmArgs p) {
     constexpr int SS = 64 + 4;
     float* stage_f = reinterpret_cast<float*>(lds) + wave * (32 * SS);
     constexpr int F4R = 64 / 4;
+    float bvj[NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int j = 0; j < NI; ++j) bvj[j] = p.bias ? p.bias[n0 + wn * 64 + j * 32 + l31] : 0.f;
+    dispatch_act(p.act, [&](auto AC) {
+        constexpr int ACT = decltype(AC)::value;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage_f[acc_row(r, h) * SS + j * 32 + l31] =
-                    apply_act(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bv, p.act);
-        }
-        __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < NI; ++j) {
 #pragma unroll
-        for (int it = 0; it < (32 * F4R) / 64; ++it) {
-            const int idx = lane + 64 * it;
-            const int rr = idx / F4R, c4 = (idx % F4R) * 4;
-            const int row = m0 + wm * 128 + i * 32 + rr, col = n0 + wn * 64 + c4;
-            if (row < p.M) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + rr * SS + c4);
-                if (p.R) v = with_r4(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col), p.act);
-                if (p.c_split)
-                    tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, 22);
-                else
-                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                for (int r = 0; r < 16; ++r)
+                    stage_f[acc_row(r, h) * SS + j * 32 + l31] =
+                        apply_act_c<ACT>(acc[i][j][r] * (1.f / (E::SA * E::SW)) + bvj[j]);
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * F4R) / 64; ++it) {
+                const int idx = lane + 64 * it;
+                const int rr = idx / F4R, c4 = (idx % F4R) * 4;
+                const int row = m0 + wm * 128 + i * 32 + rr, col = n0 + wn * 64 + c4;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + rr * SS + c4);
+                    if (p.R) v = with_r4_c<ACT>(v, *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + col));
+                    if (p.c_split)
+                        tocvp_store_planes4(p.C, (size_t)row * NS * p.N + col, (size_t)p.N, v, 22);
+                    else
+                        *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-    }
+    });
 }
 
 // W (N, K) fp32 -> fragment-order bf16 planes Wf[nb][ks][plane][lane][8]
