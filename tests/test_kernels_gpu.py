@@ -366,7 +366,8 @@ def test_metric_tracker_surface(tmp_path):
         MetricTracker(metrics=["lpips"])
 
 
-@pytest.mark.parametrize("Cin,Cout,S,up", [(128, 64, 24, False), (64, 128, 16, True), (192, 32, 40, False)])
+@pytest.mark.parametrize("Cin,Cout,S,up", [(128, 64, 24, False), (64, 128, 16, True), (192, 32, 40, False),
+                                           (128, 64, 16, False), (64, 32, 16, False), (128, 64, 8, True)])   # 16-wide: narrow tiles
 def test_conv3x3_scale_shift_upsample(Cin, Cout, S, up):
     k = _k()
     x = rnd("c3x", (2, S, S, Cin))
@@ -1008,7 +1009,8 @@ def test_gemm_chunk_resident_rejects_bad_arguments():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("Cin,Cout,S,n,relu", [(128, 64, 16, 3, True), (64, 128, 8, 2, True), (128, 32, 40, 2, False)])
+@pytest.mark.parametrize("Cin,Cout,S,n,relu", [(128, 64, 16, 3, True), (64, 128, 8, 2, True), (128, 32, 40, 2, False),
+                                               (64, 32, 16, 2, False), (96, 64, 32, 1, True)])
 def test_conv3x3_up2_phases_equal_the_conv_over_the_upsampled_image(Cin, Cout, S, n, relu):
     """
     tocvp_conv3x3_up2_f16x3_f32: "Upsample(scale_factor=2) -> Conv2d(k3, p1)" of the DINOSAUR image head (reference

@@ -182,10 +182,13 @@ __device__ __forceinline__ void split4_f16(f32x4 v, float scale, unsigned char* 
 // exactly when its source pixel is).  Four phases (blockIdx.z = 2 a + b) x four taps = 16 tap products per source pixel
 // instead of 36: 2.25x fewer FLOPs than the conv over the upsampled image, same result up to the fp32 rounding of the
 // tap sums.  p.H, p.W = source size, weights (4 phases, 4 taps, Cout, Cin), output (nimg, 2 H, 2 W, Cout).
-template <int NB, int KS>
+// NARROW: images at most 16 pixels wide (the 16 x 16 patch grid of the image head): a 16 x 16 pixel tile whose 32-pixel MFMA
+// blocks hold TWO image rows of 16 pixels instead of one row of 32 (an 8 x 32 tile would compute 16 columns of padding).
+template <int NB, int KS, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
     constexpr bool PH = KS == 2;
-    constexpr int IH = TH + KS - 1, IW = TW + KS - 1, NTAP = KS * KS;
+    constexpr int TH_ = NARROW ? 16 : TH, TW_ = NARROW ? 16 : TW;
+    constexpr int IH = TH_ + KS - 1, IW = TW_ + KS - 1, NTAP = KS * KS;
     const int pa = PH ? (int)blockIdx.z >> 1 : 0, pb = PH ? (int)blockIdx.z & 1 : 0;
     const int oy0 = PH ? pa - 1 : -(KS / 2), ox0 = PH ? pb - 1 : -(KS / 2);     // first tap relative to the output pixel
     constexpr int COUTB = NB * 32;
@@ -198,9 +201,12 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int tiles_x = (p.W + TW - 1) / TW, tiles = tiles_x * (p.H / TH);
+    const int tiles_x = (p.W + TW_ - 1) / TW_, tiles = tiles_x * (p.H / TH_);
     const int img = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    const int ty0 = (tile / tiles_x) * TH_, tx0 = (tile % tiles_x) * TW_;
+    // pixel l31 of a wave's 32-pixel block m: row (NARROW: 4 wave + 2 m + l31 / 16, else 2 wave + m), column (l31 % 16 / l31)
+    const int apy = NARROW ? (l31 >> 4) : 0, apx = NARROW ? (l31 & 15) : l31;
+    constexpr int WROWS = NARROW ? 4 : 2, MSTEP = NARROW ? 2 : 1;
     const int co0 = blockIdx.y * COUTB;
     const int SH = p.upsample ? p.H / 2 : p.H, SW = p.upsample ? p.W / 2 : p.W;
     const int sh = p.upsample ? 1 : 0;
@@ -267,15 +273,15 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
             if (tap + 1 < NTAP) wload(tap + 1, ch);
             __builtin_amdgcn_sched_barrier(0);
             const int dy = tap / KS, dx = tap % KS;
-            const unsigned char* a_base = in_s + ((2 * wave + dy) * IW + l31 + dx) * ROWB + h * 16;
+            const unsigned char* a_base = in_s + ((WROWS * wave + apy + dy) * IW + apx + dx) * ROWB + h * 16;
             const unsigned char* b_base = w_s + buf * COUTB * ROWB + l31 * ROWB + h * 16;
 #pragma unroll
             for (int ks = 0; ks < CH / 16; ++ks) {
                 h16x8 ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    ah[m] = *reinterpret_cast<const h16x8*>(a_base + m * IW * ROWB + ks * 32);
-                    al[m] = *reinterpret_cast<const h16x8*>(a_base + m * IW * ROWB + ks * 32 + CH * 2);
+                    ah[m] = *reinterpret_cast<const h16x8*>(a_base + m * MSTEP * IW * ROWB + ks * 32);
+                    al[m] = *reinterpret_cast<const h16x8*>(a_base + m * MSTEP * IW * ROWB + ks * 32 + CH * 2);
                 }
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
@@ -303,16 +309,17 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
         const float sc = (p.scale ? p.scale[co] : 1.f) * UNSCALE, sf = p.shift[co];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int oy = ty0 + 2 * wave + m;
-            float* yrow = PH ? p.y + (((size_t)img * 2 * p.H + 2 * oy + pa) * 2 * p.W + pb) * p.Cout + co
-                             : p.y + (((size_t)img * p.H + oy) * p.W) * p.Cout + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ox = tx0 + acc_row(r, h);
+                const int pp = acc_row(r, h);
+                const int oy = ty0 + WROWS * wave + MSTEP * m + (NARROW ? (pp >> 4) : 0);
+                const int ox = tx0 + (NARROW ? (pp & 15) : pp);
                 if (ox < p.W) {
                     float v = fmaf(acc[m][n][r], sc, sf);
                     if (p.relu) v = fmaxf(v, 0.f);
-                    yrow[(size_t)(PH ? 2 * ox : ox) * p.Cout] = v;
+                    float* yp = PH ? p.y + ((((size_t)img * 2 * p.H + 2 * oy + pa) * 2 * p.W + pb) + 2 * ox) * p.Cout + co
+                                   : p.y + (((size_t)img * p.H + oy) * p.W + ox) * p.Cout + co;
+                    *yp = v;
                 }
             }
         }
@@ -409,7 +416,11 @@ static int launch_convk_f16x3(const float* x, const float* wp, const float* scal
     Conv3Args a{x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2 ? 1 : 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 g64((unsigned)(nimg * tiles), Cout / 64), g32((unsigned)(nimg * tiles), Cout / 32);
-    if (ksize == 3) {
+    if (ksize == 3 && W <= 16 && (H % 16) == 0) {                  // narrow images: 16 x 16 tiles (two rows per MFMA block)
+        const unsigned nt = (unsigned)(nimg * (size_t)(H / 16));
+        if (Cout % 64 == 0) hipLaunchKernelGGL((convk_f16x3_kernel<2, 3, true>), dim3(nt, Cout / 64), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((convk_f16x3_kernel<1, 3, true>), dim3(nt, Cout / 32), dim3(256), 0, s, a);
+    } else if (ksize == 3) {
         if (Cout % 64 == 0) hipLaunchKernelGGL((convk_f16x3_kernel<2, 3>), g64, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((convk_f16x3_kernel<1, 3>), g32, dim3(256), 0, s, a);
     } else {
@@ -436,7 +447,11 @@ extern "C" int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, 
     if (nimg == 0) return TOCVP_OK;
     Conv3Args a{x, wphase, scale, shift, y, nimg, SH, SW, Cin, Cout, relu, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (Cout % 64 == 0)
+    if (SW <= 16 && (SH % 16) == 0) {                              // narrow source images: 16 x 16 tiles
+        const unsigned nt = (unsigned)(nimg * (size_t)(SH / 16));
+        if (Cout % 64 == 0) hipLaunchKernelGGL((convk_f16x3_kernel<2, 2, true>), dim3(nt, Cout / 64, 4), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((convk_f16x3_kernel<1, 2, true>), dim3(nt, Cout / 32, 4), dim3(256), 0, s, a);
+    } else if (Cout % 64 == 0)
         hipLaunchKernelGGL((convk_f16x3_kernel<2, 2>), dim3((unsigned)(nimg * tiles), Cout / 64, 4), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((convk_f16x3_kernel<1, 2>), dim3((unsigned)(nimg * tiles), Cout / 32, 4), dim3(256), 0, s, a);

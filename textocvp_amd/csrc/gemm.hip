@@ -133,15 +133,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     if (!p.rowvec && (p.ldc & 3) == 0 && (!p.R || (p.ldr & 3) == 0)) {
         float* stage = lds + wave * (32 * SS);
         constexpr int F4R = WN / 4;
+        float bvj[NI];                                                // one load per column block
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            bvj[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        }
+        // (the activation switch hoisted out of the unrolled loops: inside them every staged element carried a ladder of
+        // scalar branches and the inlined erff of the GELU it did not take)
+        const int act_sel = p.act == TOCVP_ACT_RELU ? 1 : (p.act == TOCVP_ACT_GELU ? 2 : 0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            if (act_sel == 1) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = n0 + wn * WN + j * 32 + l31;
-                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[acc_row(r, h) * SS + j * 32 + l31] = apply_act(acc[i][j][r] + bv, p.act);
+                    for (int r = 0; r < 16; ++r) stage[acc_row(r, h) * SS + j * 32 + l31] = fmaxf(acc[i][j][r] + bvj[j], 0.0f);
+            } else if (act_sel == 2) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[acc_row(r, h) * SS + j * 32 + l31] = apply_act(acc[i][j][r] + bvj[j], TOCVP_ACT_GELU);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stage[acc_row(r, h) * SS + j * 32 + l31] = acc[i][j][r] + bvj[j];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
