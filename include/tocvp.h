@@ -148,6 +148,16 @@ int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_frag, const f
  * ------------------------------------------------------------------------------------------- */
 int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
                             void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream);
+/* The same structure for mid-size row counts (600 .. 10 000 rows: the predictor's products at small evaluation batches,
+ * models/Blocks/attention.py:167-175, 355-359, 428-432): 64 rows x 256 outputs per workgroup, two workgroups per CU, A in
+ * 128-deep chunks by LDS-DMA, weights from L2 in fragment order; N % 256 == 0, K % 128 == 0.  With a workspace
+ * (tocvp_gemm_f16mid_ws_bytes() bytes, 16-byte aligned, ZERO before its first use, one per stream that may run
+ * concurrently) K is split over idle CUs: every slice parks its raw accumulators, the last arriver of a tile adds the
+ * slices in slice order (deterministic; the arrival counters re-arm themselves) and runs the epilogue.  ws == NULL: never
+ * split, and then bit-identical to tocvp_gemm_bf16wfrag_f32 on the same operands.  Arguments as tocvp_gemm_f16chunk_f32. */
+size_t tocvp_gemm_f16mid_ws_bytes(void);
+int tocvp_gemm_f16mid_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr, void* C,
+                          int c_split, int ldc, int M, int N, int K, int act, void* ws, size_t ws_bytes, void* stream);
 int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
                             const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
                             int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);

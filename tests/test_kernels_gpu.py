@@ -737,7 +737,8 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
     k = _k()
     monkeypatch.setattr(k, "_GEMM_P2", True)                    # the persistent planes kernel is opt-in
     monkeypatch.setattr(k, "_GEMM_P2_MIN_ROWS", 1)              # every plane-input product on the planes kernel
-    monkeypatch.setattr(k, "_GEMM_CHUNK", False)                # (not on the round-4 chunk-resident kernel)
+    monkeypatch.setattr(k, "_GEMM_CHUNK", False)                # (not on the round-4 chunk-resident kernels)
+    monkeypatch.setattr(k, "_GEMM_MID", False)
     x = rnd("p3x", (M, Kd), "normal")
     w = rnd("p3w", (N, Kd), "uniform", Kd ** -0.5)
     b = rnd("p3b", (N,), "uniform", 0.1)
@@ -970,6 +971,7 @@ def test_gemm_chunk_resident_equals_the_in_loop_split_kernel(M, N, Kd, monkeypat
         for act in (k.ACT_NONE, k.ACT_RELU, k.ACT_GELU):
             for res, osplit in ((None, 0), (rd, 0), (None, 22)):
                 monkeypatch.setattr(k, "_GEMM_CHUNK", False)
+                monkeypatch.setattr(k, "_GEMM_MID", False)
                 a = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
                 monkeypatch.setattr(k, "_GEMM_CHUNK", True)
                 names = []
@@ -1040,3 +1042,48 @@ def test_conv3x3_up2_phases_equal_the_conv_over_the_upsampled_image(Cin, Cout, S
     got1 = k.conv3x3_up2(xd, k.pack_conv3x3_up2_weights(wd), None, sfd, relu=False)
     ref1 = (torch.nn.functional.conv2d(up, w.double(), padding=1) + sf.double()[None, :, None, None]).permute(0, 2, 3, 1)
     assert (got1.cpu().double() - ref1).abs().max().item() < 2e-6 * max(1.0, ref1.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2400, 2048, 512), (9600, 512, 2048), (960, 1536, 512), (3841, 256, 128), (65, 768, 1024)])
+def test_gemm_chunk_mid_size_form(M, N, Kd, monkeypatch):
+    """
+    tocvp_gemm_f16mid_f32 (csrc/gemm_f16c.hip, mid-size form: 64 x 256 tiles, two workgroups per CU, A chunks by LDS-DMA,
+    weights streamed) -- the predictor's products at small evaluation batches (reference attention.py:167-175, 355-359,
+    428-432).  Without split-K BIT-IDENTICAL to tocvp_gemm_bf16wfrag_f32 on the same planes (every activation, residual,
+    plane output, ragged rows); with split-K through the workspace: repeatable bit for bit, fp32-class against float64, the
+    arrival counters end at zero.
+    """
+    k = _k()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, Kd, generator=g)
+    w, b = torch.randn(N, Kd, generator=g) / Kd ** 0.5, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    xd, wd, bd, rd = (t.to(DEV) for t in (x, w, b, r))
+    v = torch.clamp(xd * 256.0, -65504.0, 65504.0)
+    hi = v.to(torch.float16)
+    xp = k.SplitAct(torch.stack([hi, (v - hi.float()).to(torch.float16)], dim=1).contiguous(), (M, Kd))
+    monkeypatch.setattr(k, "_GEMM_CHUNK", False)
+    monkeypatch.setattr(k, "_GEMM_MID_MIN_TILES", 1)
+    ref = x.double() @ w.double().t() + b.double()
+    with k.gemm_precision("f16x3"):
+        for act in (k.ACT_NONE, k.ACT_RELU, k.ACT_GELU):
+            for res, osplit in ((None, 0), (rd, 0), (None, 22)):
+                monkeypatch.setattr(k, "_GEMM_MID", False)
+                a = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                monkeypatch.setattr(k, "_GEMM_MID", True)
+                monkeypatch.setattr(k, "_GEMM_MID_SPLITK", False)
+                c = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                monkeypatch.setattr(k, "_GEMM_MID_SPLITK", True)
+                d1 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                d2 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                if osplit:
+                    a, c, d1, d2 = (t.planes.view(torch.int16) for t in (a, c, d1, d2))
+                assert torch.equal(a, c), (act, res is not None, osplit)
+                assert torch.equal(d1, d2)
+                if not osplit:
+                    assert (d1 - a).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+        got = k.linear(xp, wd, bd)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 5e-6 * max(1.0, ref.abs().max().item())
+    wk = k._mid_workspace(xd.device, torch.cuda.current_stream().cuda_stream)[0]
+    assert int(wk[:4096].view(torch.int32).abs().sum()) == 0

@@ -369,6 +369,254 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same structure for MID-SIZE row counts (small evaluation batches: 600 .. 10 000 rows of the predictor's products,
+// reference models/Blocks/attention.py:167-175, 355-359, 428-432).  The two-operand kernels (gemm_bf16.hip, 64 x 64 tiles)
+// walk K in 64-deep tiles of load -> split -> LDS store -> barrier -> 12 MFMAs per wave: ~1200 cycles per k-tile, 41 us for
+// 2400 x 512 x 2048 whose products take 6 us of the matrix pipe.  Here:
+//   * a workgroup owns 64 rows x 256 outputs (4 waves, each 64 rows x 64 outputs: 2 x 2 accumulator tiles), 64 KB of LDS
+//     (two 32 KB chunk images) and 256 registers -> TWO workgroups per CU, one computing while the other waits;
+//   * A in 128-deep chunks by LDS-DMA (8 instructions per wave and chunk, one barrier per chunk), weights from L2 in
+//     fragment order through a ring of four 16-deep steps (three ahead);
+//   * SPLIT-K over chunk ranges when the tiles do not fill the chip: every slice parks its raw accumulators (lane order,
+//     64 KB) in a per-stream workspace, counts itself in, and the LAST arriver of a tile adds the slices in slice order
+//     (deterministic), then runs the epilogue (hand-off as cdna_hip_programming.md Guideline 16);
+//   * epilogue through the 64 KB of LDS in one pass (raw accumulators, 16-byte-chunk swizzle), scale + ONE bias quad per
+//     lane, activation, residual, fp32 rows or fp16 planes on the way out.
+// Unsplit (S = 1) it is bit-identical to tocvp_gemm_bf16wfrag_f32; split, the k order inside a slice is kept and the slices
+// are added in order (differs from the unsplit sum in the last bits, every run the same).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MBM = 64;                      // rows per workgroup
+constexpr int MBN = 256;                     // outputs per workgroup
+constexpr int MABYTES = MBM * AROW;          // 32 KB chunk image
+constexpr int MREC = MBM * MBN;              // floats per parked record (64 KB)
+constexpr int MID_CTR_BYTES = 16384;         // 4096 tile counters
+constexpr int MID_RECORDS = 1024;            // 64 MB of records
+
+struct MidArgs {
+    const unsigned char* A; const unsigned char* Wf; const float* bias; const float* R; int ldr;
+    void* C; int ldc; int c_split;
+    int M, N, K, col_tiles, S;
+    float* ws_part; unsigned* ws_ctr;
+};
+
+template <int ACT, bool CSPLIT, bool HASR>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * MABYTES];
+    typedef const __attribute__((address_space(1))) unsigned char* gptr;
+    typedef const __attribute__((address_space(1))) f16x8* gv8;
+
+    const int slice = (int)blockIdx.x % p.S, tile = (int)blockIdx.x / p.S;
+    const int rt = tile / p.col_tiles, ct = tile % p.col_tiles;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int KS = p.K / 16, nchunk = p.K / CK;
+    const int c0 = nchunk * slice / p.S, c1 = nchunk * (slice + 1) / p.S;      // chunk range of this slice (never empty: S <= nchunk)
+    const int m0 = rt * MBM, n0 = ct * MBN;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned x15 = (unsigned)(l31 & 15);
+
+    // A chunk: 32 instructions of 1 KiB (2 rows x 512 B), 8 per wave; source-side chunk swizzle as above
+    unsigned voff_a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 2 * (w * 8 + i) + (lane >> 5);
+        const int lc = (lane & 31) ^ (row & 15);
+        const int grow = min(m0 + row, p.M - 1);
+        voff_a[i] = (unsigned)((((size_t)grow * 2 + (lc >> 4)) * p.K + (lc & 15) * 8) * 2);
+    }
+    const unsigned a_lds = (unsigned)(size_t)lds;
+    auto dma_a = [&](unsigned buf_off, int c, int i0, int i1) {
+        const unsigned char* base = p.A + (size_t)c * (CK * 2);
+        asm volatile("" : "+s"(base));
+        const gptr g = (gptr)base;
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const gptr src = g + voff_a[i];
+            const unsigned dst = a_lds + buf_off + (unsigned)((w * 8 + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+        }
+    };
+    // weight fragments of one 16-deep step: output blocks 2 w, 2 w + 1 of this column tile, both planes
+    const unsigned char* const wbase = p.Wf + (size_t)(n0 / 32 + 2 * w) * KS * 2048;
+    const int gmax = 8 * c1 - 1;
+    auto load_w = [&](f16x8 (&b)[4], int g) {
+        g = min(g, gmax);                                            // past the end of the slice: a harmless re-load
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) {
+            const unsigned char* base = wbase + ((size_t)jl * KS + g) * 2048;
+            asm volatile("" : "+s"(base));
+            const gptr gp = (gptr)base + lane16;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) b[2 * jl + pl] = *(gv8)(gp + pl * 1024);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Frag { f16x8 v[2][2]; };
+    auto read_a = [&](Frag& f, unsigned buf_off, int s) {
+        const unsigned char* ab = lds + buf_off + l31 * AROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                f.v[i][pl] = *reinterpret_cast<const f16x8*>(ab + i * 32 * AROW + (((unsigned)(pl * 16 + 2 * s + h) ^ x15) << 4));
+    };
+    auto mfma_step = [&](const Frag& f, const f16x8 (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                acc[i][jl] = mfma16(b[2 * jl + 1], f.v[i][0], acc[i][jl]);     // act hi x w lo
+                acc[i][jl] = mfma16(b[2 * jl + 0], f.v[i][1], acc[i][jl]);     // act lo x w hi
+                acc[i][jl] = mfma16(b[2 * jl + 0], f.v[i][0], acc[i][jl]);     // act hi x w hi
+            }
+    };
+
+    f16x8 wr[4][4];                                                  // ring of steps, slot = step & 3
+    Frag F0, F1;
+    dma_a(0, c0, 0, 8);
+    load_w(wr[0], 8 * c0);
+    load_w(wr[1], 8 * c0 + 1);
+    load_w(wr[2], 8 * c0 + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_a(F0, 0, 0);
+    unsigned cur = 0, oth = MABYTES;
+#pragma unroll 1
+    for (int c = c0; c < c1; ++c) {
+        const bool more = c + 1 < c1;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int g = 8 * c + s;
+            Frag& fc = (s & 1) ? F1 : F0;
+            Frag& fn = (s & 1) ? F0 : F1;
+            load_w(wr[(s + 3) & 3], g + 3);
+            if (s < 4 && more) dma_a(oth, c + 1, 2 * s, 2 * s + 2);
+            if (s < 7) {
+                read_a(fn, cur, s + 1);
+            } else {
+                // the DMA instructions of the next chunk were issued in steps 0 .. 3, 16 weight-fragment loads ago
+                asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (more) read_a(fn, oth, 0);
+            }
+            mfma_step(fc, wr[s & 3]);
+            if (s < 4) weave<12, 4, 6>();
+            else weave<12, 4, 4>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned t_ = cur;
+        cur = oth;
+        oth = t_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the fragment loads past the end
+
+    // ---- split K: park, count in, the last arriver adds the slices in slice order
+    if (p.S > 1) {
+        float* mine = p.ws_part + ((size_t)tile * p.S + slice) * MREC + ((size_t)w * 64 * 16 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(mine + ((i * 2 + j) * 4 + g) * 256) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* arrived = reinterpret_cast<unsigned*>(lds);        // the chunk images are dead
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(p.ws_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)(p.S - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.ws_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            *arrived = old;
+        }
+        __syncthreads();
+        if (*arrived != (unsigned)(p.S - 1)) return;
+        __syncthreads();                                             // everyone has read the flag before LDS is reused
+        const float* rec0 = p.ws_part + (size_t)tile * p.S * MREC + ((size_t)w * 64 * 16 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int sl = 0; sl < p.S; ++sl) {
+            f32x4 v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = *reinterpret_cast<const f32x4*>(rec0 + (size_t)sl * MREC + e * 256);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[e >> 3][(e >> 2) & 1][4 * (e & 3) + u] += v[e][u];
+        }
+    }
+
+    // ---- epilogue: register quad g of acc[i][j] = outputs n0 + 64 w + 32 j + 8 g + 4 h .. + 3 of row 32 i + l31; 64 rows x
+    // 256 floats through LDS (row = 64 chunks of 16 B, physical chunk = logical ^ (row & 15)); a lane writes out the same
+    // four columns of rows (t >> 6) + 4 k
+    __syncthreads();
+    {
+        unsigned char* const ost = lds;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned lc = (unsigned)(16 * w + 8 * j + 2 * g + h);
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(ost + (32 * i + l31) * 1024 + ((lc ^ x15) << 4)) = v;
+                }
+        __syncthreads();
+        const int lcq = t & 63, rsel = t >> 6;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4 * lcq);
+#pragma unroll 1
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+            f32x4 rq[8], vq[8];
+            if (HASR) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = m0 + rsel + 4 * (it0 + k);
+                    rq[k] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(row, p.M - 1) * p.ldr + n0 + 4 * lcq);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rl = rsel + 4 * (it0 + k);
+                vq[k] = *reinterpret_cast<const f32x4*>(ost + rl * 1024 + (((unsigned)lcq ^ (unsigned)(rl & 15)) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = m0 + rsel + 4 * (it0 + k);
+                f32x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = act_of(vq[k][u] * (1.f / (SA * SW)) + bq[u], ACT);
+                if (HASR) v += rq[k];
+                if (row < p.M) {
+                    if (CSPLIT) tocvp_store_planes4(p.C, (size_t)row * 2 * p.N + n0 + 4 * lcq, (size_t)p.N, v, 22);
+                    else *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + n0 + 4 * lcq) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef TOCVP_GC_STAMP
@@ -430,5 +678,55 @@ extern "C" int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag,
     else GC_LAUNCH_SR(TOCVP_ACT_NONE);
 #undef GC_LAUNCH_SR
 #undef GC_LAUNCH
+    return tocvp_launch_status();
+}
+
+extern "C" size_t tocvp_gemm_f16mid_ws_bytes(void) { return (size_t)MID_CTR_BYTES + (size_t)MID_RECORDS * MREC * sizeof(float); }
+
+extern "C" int tocvp_gemm_f16mid_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
+                                     void* C, int c_split, int ldc, int M, int N, int K, int act, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    TOCVP_CHECK_ARG(A_planes && W_frag && C && M >= 0 && N > 0 && K > 0);
+    TOCVP_CHECK_ARG((N % MBN) == 0 && (K % CK) == 0);
+    TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
+    TOCVP_CHECK_ARG(c_split || (ldc >= N && (ldc & 3) == 0));
+    TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0));
+    TOCVP_CHECK_ARG((size_t)M * 2 * K * 2 < 0xffffffffull);
+    TOCVP_CHECK_ARG(ws == nullptr || (ws_bytes >= tocvp_gemm_f16mid_ws_bytes() && tocvp_aligned16(ws)));
+    if (!tocvp_aligned16(A_planes) || !tocvp_aligned16(W_frag) || !tocvp_aligned16(C) || (bias && !tocvp_aligned16(bias)) ||
+        (R && !tocvp_aligned16(R)))
+        return TOCVP_EALIGN;
+    if (M == 0) return TOCVP_OK;
+    const int row_tiles = (M + MBM - 1) / MBM, col_tiles = N / MBN, tiles = row_tiles * col_tiles, nchunk = K / CK;
+    // slices of K while the workgroups fit the chip's 2 x CUs slots, every slice at least two chunks deep
+    int S = 1;
+    if (ws) {
+        static const int smax = []() { const char* e = getenv("TOCVP_GEMM_MID_SMAX"); return e ? atoi(e) : 8; }();
+        while (2 * S <= smax && tiles * 2 * S <= 2 * gc_cus() && nchunk / (2 * S) >= 2 && tiles * 2 * S <= MID_RECORDS &&
+               tiles <= MID_CTR_BYTES / 4)
+            S *= 2;
+    }
+    MidArgs p{static_cast<const unsigned char*>(A_planes), static_cast<const unsigned char*>(W_frag), bias, R, ldr, C, ldc,
+              c_split, M, N, K, col_tiles, S,
+              ws ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + MID_CTR_BYTES) : nullptr,
+              static_cast<unsigned*>(ws)};
+    const dim3 grid((unsigned)(tiles * S));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GM_LAUNCH(A_, S_, R_) hipLaunchKernelGGL((gemm_f16x3_mid_kernel<A_, S_, R_>), grid, dim3(256), 0, st, p)
+#define GM_LAUNCH_SR(A_)                                  \
+    do {                                                  \
+        if (c_split) {                                    \
+            if (R) GM_LAUNCH(A_, true, true);             \
+            else GM_LAUNCH(A_, true, false);              \
+        } else {                                          \
+            if (R) GM_LAUNCH(A_, false, true);            \
+            else GM_LAUNCH(A_, false, false);             \
+        }                                                 \
+    } while (0)
+    if (act == TOCVP_ACT_RELU) GM_LAUNCH_SR(TOCVP_ACT_RELU);
+    else if (act == TOCVP_ACT_GELU) GM_LAUNCH_SR(TOCVP_ACT_GELU);
+    else GM_LAUNCH_SR(TOCVP_ACT_NONE);
+#undef GM_LAUNCH_SR
+#undef GM_LAUNCH
     return tocvp_launch_status();
 }

@@ -84,6 +84,11 @@ _SIGNATURES = {
     "tocvp_conv3x3_up2_f16x3_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_gemm_f16mid_ws_bytes": (ctypes.c_size_t, []),
+    "tocvp_gemm_f16mid_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -454,6 +459,27 @@ _GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
 # kernels win; 9600 x 512 x 2048 = 75 tiles: 118 vs 103 us, 9600 x 1536 x 512 = 225 tiles: 55 vs 63 us).  TOCVP_GEMM_CHUNK=0: off
 _GEMM_CHUNK = os.environ.get("TOCVP_GEMM_CHUNK", "1") != "0"
 _GEMM_CHUNK_MIN_TILES = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_TILES", "192"))
+# mid-size form of the chunk kernel (64 x 256 tiles, two workgroups per CU, split-K through a per-stream workspace) for
+# plane-input products of _GEMM_MID_MIN_ROWS .. _GEMM_MID_MAX_ROWS rows (TOCVP_GEMM_MID=0: off)
+_GEMM_MID = os.environ.get("TOCVP_GEMM_MID", "1") != "0"
+# from _GEMM_MID_MIN_TILES tiles of 64 x 256 (fewer leave CUs idle: 2400 x 512 x 2048 = 76 tiles runs 34.5 us against 31.3 us
+# on the two-operand planes kernel, 2400 x 1536 x 512 = 228 tiles 16.8 against 21.1 us).  Split-K through the workspace is
+# built and deterministic but measured SLOWER than the unsplit launch (2400 x 1536 x 512: 39.7 us with two slices -- the
+# agent-scope release in front of the arrival count), so it is opt-in (TOCVP_GEMM_MID_SPLITK=1)
+_GEMM_MID_MIN_TILES = int(os.environ.get("TOCVP_GEMM_MID_MIN_TILES", "192"))
+_GEMM_MID_MAX_ROWS = int(os.environ.get("TOCVP_GEMM_MID_MAX_ROWS", "16384"))
+_GEMM_MID_SPLITK = os.environ.get("TOCVP_GEMM_MID_SPLITK", "0") != "0"
+_MID_WS = {}
+
+
+def _mid_workspace(device, stream):
+    key = (device.index, stream)
+    rec = _MID_WS.get(key)
+    if rec is None:
+        nbytes = lib().tocvp_gemm_f16mid_ws_bytes()
+        wk = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+        rec = _MID_WS[key] = (wk, ctypes.c_void_p(wk.data_ptr()), nbytes)
+    return rec
 _GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
@@ -778,6 +804,19 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
                                               None if r2 is None else r2[r0:].data_ptr(), N, out[r0:].data_ptr(),
                                               int(bool(out_split)), N, mb, N, K, int(act), _stream()),
                 "tocvp_gemm_f16chunk_f32"))
+    elif (frag_ok and pre_split and nsplit == 22 and _GEMM_MID and rowvec is None and N % 256 == 0 and K % 128 == 0 and
+            M <= _GEMM_MID_MAX_ROWS and ((M + 63) // 64) * (N // 256) >= _GEMM_MID_MIN_TILES and M * 4 * K < 2 ** 32 and
+            act in (ACT_NONE, ACT_RELU, ACT_GELU)):
+        # 64 x 256 tiles, A chunks by LDS-DMA, weights streamed, split-K over idle CUs (gemm_f16c.hip, mid-size form)
+        ws = _split_weight(w, 22, frag=True)
+        st = _stream()
+        wk_ptr, wk_bytes = (None, 0)
+        if _GEMM_MID_SPLITK:
+            _, wk_ptr, wk_bytes = _mid_workspace(w.device, st)
+        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
+            lib().tocvp_gemm_f16mid_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out), int(bool(out_split)), N, M, N,
+                                        K, int(act), wk_ptr, wk_bytes, st),
+            "tocvp_gemm_f16mid_f32"))
     elif (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
             M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
         # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)

@@ -46,7 +46,10 @@ _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "wide")
 _PRESPLIT_MLP = os.environ.get("TOCVP_PRESPLIT_MLP", "1") != "0"
 _PRESPLIT_MIN_N = 1536
 # B=32 (9600 rows) measures 1.5 % slower with planes, B=128 (38400 rows) 2 % faster (round 3, two GEMMs per MLP)
-_PRESPLIT_MIN_ROWS = int(os.environ.get("TOCVP_PRESPLIT_MIN_ROWS", "16384"))
+# (round 4, second half: with the mid-size chunk GEMM -- 64 x 256 tiles, A by LDS-DMA -- planes pay from ~2600 rows (B = 8, 2400 rows: 2456-2464 vs 2470-2513 frames/s with them; B = 32: 3674-3678 vs 3554-3559): at 9600
+# rows 77.9 / 67.5 / 54.7 us against 87.3 / 78.4 / 62.0 us with fp32 input on the MLP down / up / qkv products; below that the
+# skinny split-K kernels on fp32 input stay faster)
+_PRESPLIT_MIN_ROWS = int(os.environ.get("TOCVP_PRESPLIT_MIN_ROWS", "2600" if K._GEMM_MID else "16384"))
 # the persistent chunk-resident GEMM (csrc/gemm_f16c.hip) for the predictor's plane-input products: 189 vs 222 us isolated on
 # the qkv projection at 38400 rows, but its workgroups need a whole CU each and stall the decoder's on the other stream:
 # A/B at B = 128 on one box 3997 / 4002 (on) vs 4026 / 4027 frames/s (off) with the decode overlapped, 3894 / 3888 vs
