@@ -521,21 +521,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
 
     // ---- split K: park, count in, the last arriver adds the slices in slice order
     if (p.S > 1) {
-        float* mine = p.ws_part + ((size_t)tile * p.S + slice) * MREC + ((size_t)w * 64 * 16 + lane) * 4;
+        {
+            // write-through (sc1) 16-byte stores: the record leaves the XCD's L2 as it is written, so no release fence is
+            // needed in front of the arrival count (its L2 write-back cost ~6.5 us per workgroup in gemm_bf16.hip's split-K,
+            // and 23 us on a two-slice 2400 x 1536 x 512 launch here)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ws_part, 0, MID_RECORDS * MREC * 4, 0x00020000);
+            const unsigned off0 = (unsigned)((((size_t)tile * p.S + slice) * MREC + ((size_t)w * 64 * 16 + lane) * 4) * sizeof(float));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(mine + ((i * 2 + j) * 4 + g) * 256) =
-                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
+                                                               off0 + ((i * 2 + j) * 4 + g) * 1024, 0, 16);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its stores
         __syncthreads();
         unsigned* arrived = reinterpret_cast<unsigned*>(lds);        // the chunk images are dead
         if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned old = __hip_atomic_fetch_add(p.ws_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)(p.S - 1)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
