@@ -216,6 +216,17 @@ int tocvp_mha_f32(const float* Q, int ldq, const float* K, int ldk, const float*
 int tocvp_mha_qk16_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                        float* O, int ldo, int B, int H, int Tq, int Tk, int dh, float scale,
                        const int32_t* key_len, void* stream);
+/* Sequence lengths one past a multiple of the 128-query tile (the ViT's 256 patches + class token, timm_encoders.py:59-70):
+ * tocvp_mha_qk16_rows_f32 = tocvp_mha_qk16_f32 on the FIRST q_rows query rows of tensors that hold Tq_total rows per sample
+ * (batch strides Tq_total * ldq / ldo), tocvp_mha_one_query_f32 = row q_row of every sample against all keys in exact fp32
+ * on the vector ALUs (one wave per (sample, head); Tk <= 1024).  Together they replace a third query tile that staged all
+ * keys and values again for one row. */
+int tocvp_mha_qk16_rows_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                            int B, int H, int Tq_total, int q_rows, int Tk, int dh, float scale, const int32_t* key_len,
+                            void* stream);
+int tocvp_mha_one_query_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                            int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale, const int32_t* key_len,
+                            void* stream);
 /* same, O written as operand planes: (B*Tq, nsplit, H*dh) bf16 (nsplit 2 or 3) or, nsplit 22,
  * (B*Tq, 2, H*dh) fp16 planes of 2^8 O */
 int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

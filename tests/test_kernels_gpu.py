@@ -1087,3 +1087,44 @@ def test_gemm_chunk_mid_size_form(M, N, Kd, monkeypatch):
     assert err < 5e-6 * max(1.0, ref.abs().max().item())
     wk = k._mid_workspace(xd.device, torch.cuda.current_stream().cuda_stream)[0]
     assert int(wk[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(24, 12, 257, 64), (70, 4, 129, 32)])
+def test_mha_tail_row_of_the_vit_sequence_length(B, H, T, dh, monkeypatch):
+    """
+    Self-attention at 128 n + 1 tokens (the ViT's 256 patches + class token, timm_encoders.py:59-70): the tile kernel runs the
+    first T - 1 query rows of tensors that hold T rows per sample (tocvp_mha_qk16_rows_f32) and the last row goes through
+    tocvp_mha_one_query_f32 (exact fp32, a wave per (sample, head)) instead of a third 128-query tile that stages every key
+    and value again for that one row.  Fused-qkv views (row stride 3 E), per-sample key lengths; against the oracle's
+    attention and against the one-launch path.
+    """
+    k = _k()
+    E = H * dh
+    qkv = rnd("tqkv", (B, T, 3 * E))
+    lengths = torch.full((B,), T, dtype=torch.int64)
+    lengths[1], lengths[B - 1] = T - 7, 131
+    key_pad = torch.arange(1, T + 1)[None, :] > lengths[:, None]
+    ref = O.attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, dh ** -0.5, key_mask=key_pad)
+    d = qkv.to(DEV)
+    kl = lengths.to(torch.int32).to(DEV)
+    names = []
+    real = k.lib()
+    monkeypatch.setattr(k, "_MHA_TAIL_ROW", True)
+    k.TIMER = type("T", (), {"wrap": staticmethod(lambda name, units, fn: (names.append(name), fn())[1])})()
+    try:
+        got = k.mha(d[..., :E], d[..., E:2 * E], d[..., 2 * E:], H, dh ** -0.5, key_len=kl)
+    finally:
+        k.TIMER = None
+    monkeypatch.setattr(k, "_MHA_TAIL_ROW", False)
+    one = k.mha(d[..., :E], d[..., E:2 * E], d[..., 2 * E:], H, dh ** -0.5, key_len=kl)
+    close(got, ref)
+    close(one, ref)
+    assert torch.equal(got[:, :T - 1], one[:, :T - 1]), "the first T - 1 rows come from the same tile kernel"
+    assert (got[:, T - 1] - one[:, T - 1]).abs().max().item() < 3e-6
+    # direct C-ABI call of the one-row kernel on another row, plain (B, T, E) tensors
+    q2, k2, v2 = (t.contiguous() for t in (d[..., :E], d[..., E:2 * E], d[..., 2 * E:]))
+    o2 = torch.zeros(B, T, E, device=DEV)
+    rc = real.tocvp_mha_one_query_f32(q2.data_ptr(), E, k2.data_ptr(), E, v2.data_ptr(), E, o2.data_ptr(), E, B, H, T, 5, T, dh,
+                                      dh ** -0.5, kl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert (o2[:, 5].cpu() - ref[:, 5]).abs().max().item() < 3e-6 and float(o2[:, 6].abs().max()) == 0.0

@@ -27,6 +27,7 @@ struct MhaArgs {
     void* Osplit; int nsplit;      // optional (B*Tq, nsplit, H*dh) bf16-plane output instead of O
     const float* bias;             // optional additive score bias (H, Tq, Tk), e.g. T5 relative positions
     int xcd;                       // XCD-aware workgroup ids (TOCVP_MHA_XCD, default 1)
+    int TqTot;                     // rows per batch of the Q / O tensors (>= Tq: the launch may cover the first Tq rows only)
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -89,10 +90,10 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     const int b = bh / p.H, head = bh % p.H;
     const int q0 = (p.xcd ? (blockIdx.x >> 3) % gx : blockIdx.x % gx) * QB;
 
-    const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + head * DH;
+    const float* Qb = p.Q + (size_t)b * p.TqTot * p.ldq + head * DH;
     const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
     const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + head * DH;
-    float* Ob = p.O ? p.O + (size_t)b * p.Tq * p.ldo + head * DH : nullptr;
+    float* Ob = p.O ? p.O + (size_t)b * p.TqTot * p.ldo + head * DH : nullptr;
 
     int kv_len = p.Tk;
     if (p.key_len) {
@@ -281,10 +282,75 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
             } else {
                 const int E = p.H * DH;
                 const int planes = p.nsplit == 22 ? 2 : p.nsplit;
-                tocvp_store_planes4(p.Osplit, ((size_t)b * p.Tq + q) * planes * E + head * DH + c,
+                tocvp_store_planes4(p.Osplit, ((size_t)b * p.TqTot + q) * planes * E + head * DH + c,
                                     (size_t)E, o, p.nsplit);
             }
         }
+    }
+}
+
+// ONE query row per (sample, head): row `q_row` of every sample against all keys, exact fp32 on the vector ALUs -- the tail of
+// sequence lengths that are one past a multiple of the 128-query tile (the ViT's 256 patches + class token,
+// timm_encoders.py:59-70: a third query tile for ONE row staged all 257 keys and values of every (sample, head) again).
+// A wave per (sample, head): lanes over keys for the scores (each lane reads whole 256-byte key rows), softmax by wave
+// reductions, lanes over the head dimension for the output (coalesced value rows, probabilities broadcast from LDS).
+constexpr int ONEQ_MAXK = 1024;
+template <int DH>
+__global__ __launch_bounds__(256) void mha_one_query_kernel(MhaArgs p, int q_row) {
+    __shared__ float qs[4][64];
+    __shared__ float ps[4][ONEQ_MAXK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= p.B * p.H) return;
+    const int b = bh / p.H, head = bh % p.H;
+    const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + head * DH;
+    const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + head * DH;
+    int kv_len = p.Tk;
+    if (p.key_len) {
+        kv_len = p.key_len[b];
+        kv_len = kv_len < 1 ? 1 : (kv_len > p.Tk ? p.Tk : kv_len);
+    }
+    if (lane < DH) qs[wave][lane] = p.Q[((size_t)b * p.TqTot + q_row) * p.ldq + head * DH + lane] * p.scale;
+    __builtin_amdgcn_wave_barrier();
+    float mx = NEG_BIG;
+    for (int j = lane; j < kv_len; j += 64) {
+        const float* kr = Kb + (size_t)j * p.ldk;
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; c += 8) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kr + c), bq = *reinterpret_cast<const f32x4*>(kr + c + 4);
+            const f32x4 qa = *reinterpret_cast<const f32x4*>(&qs[wave][c]), qb = *reinterpret_cast<const f32x4*>(&qs[wave][c + 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d0 = fmaf(a[u], qa[u], d0);
+                d1 = fmaf(bq[u], qb[u], d1);
+            }
+        }
+        const float sc = d0 + d1;
+        ps[wave][j] = sc;
+        mx = fmaxf(mx, sc);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < kv_len; j += 64) {
+        const float e = __expf(ps[wave][j] - mx);
+        ps[wave][j] = e;
+        sum += e;
+    }
+    sum = wave_sum64(sum);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < DH) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= kv_len; j += 4) {
+            a0 = fmaf(ps[wave][j], Vb[(size_t)j * p.ldv + lane], a0);
+            a1 = fmaf(ps[wave][j + 1], Vb[(size_t)(j + 1) * p.ldv + lane], a1);
+            a2 = fmaf(ps[wave][j + 2], Vb[(size_t)(j + 2) * p.ldv + lane], a2);
+            a3 = fmaf(ps[wave][j + 3], Vb[(size_t)(j + 3) * p.ldv + lane], a3);
+        }
+        for (; j < kv_len; ++j) a0 = fmaf(ps[wave][j], Vb[(size_t)j * p.ldv + lane], a0);
+        p.O[((size_t)b * p.TqTot + q_row) * p.ldo + head * DH + lane] = ((a0 + a1) + (a2 + a3)) / sum;
     }
 }
 
@@ -293,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
 static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       float* O, int ldo, void* Osplit, int nsplit, int B, int H, int Tq, int Tk,
                       int dh, float scale, const int32_t* key_len, void* stream,
-                      const float* bias = nullptr, bool qk16 = false) {
+                      const float* bias = nullptr, bool qk16 = false, int tq_tot = 0) {
     TOCVP_CHECK_ARG(Q && K && V && (O || Osplit));
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq > 0 && Tk > 0);
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
@@ -306,7 +372,8 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
         return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
     static const int xcd = []() { const char* e = getenv("TOCVP_MHA_XCD"); return e ? atoi(e) : 1; }();
-    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd};
+    TOCVP_CHECK_ARG(tq_tot == 0 || (tq_tot >= Tq && bias == nullptr));
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd, tq_tot ? tq_tot : Tq};
     // 64-query workgroups (TOCVP_MHA_NW=2) leave fewer empty query slots (300 tokens: 320 against 384) but measured
     // SLOWER in the rollout, 245 against 194 us at 128 x 8 x 300 x 300 (two A/B rounds on one box): 176 registers
     // -> two waves per SIMD instead of three, and every workgroup stages (splits, transposes) the same K / V tiles for
@@ -344,6 +411,31 @@ extern "C" int tocvp_mha_qk16_f32(const float* Q, int ldq, const float* K, int l
                                   float scale, const int32_t* key_len, void* stream) {
     return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, Tq, Tk, dh, scale, key_len,
                       stream, nullptr, true);
+}
+
+extern "C" int tocvp_mha_qk16_rows_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                                       int ldo, int B, int H, int Tq_total, int q_rows, int Tk, int dh, float scale,
+                                       const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(q_rows > 0 && q_rows <= Tq_total);
+    return mha_launch(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, 0, B, H, q_rows, Tk, dh, scale, key_len, stream, nullptr, true,
+                      Tq_total);
+}
+
+extern "C" int tocvp_mha_one_query_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                                       int ldo, int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale,
+                                       const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Q && K && V && O);
+    TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq_total > 0 && q_row >= 0 && q_row < Tq_total && Tk > 0 && Tk <= ONEQ_MAXK);
+    TOCVP_CHECK_ARG(dh == 32 || dh == 64);
+    TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh);
+    if ((ldk & 3) || !tocvp_aligned16(K)) return TOCVP_EALIGN;
+    if (B == 0) return TOCVP_OK;
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, 1, Tk, scale, key_len, nullptr, 0, nullptr, 0, Tq_total};
+    const dim3 grid((unsigned)(((long)B * H + 3) / 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dh == 64) hipLaunchKernelGGL(mha_one_query_kernel<64>, grid, dim3(256), 0, s, p, q_row);
+    else hipLaunchKernelGGL(mha_one_query_kernel<32>, grid, dim3(256), 0, s, p, q_row);
+    return tocvp_launch_status();
 }
 
 extern "C" int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V,

@@ -89,6 +89,14 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
         ctypes.c_void_p]),
+    "tocvp_mha_qk16_rows_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_mha_one_query_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -946,6 +954,10 @@ def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
 _ATTN_QK16 = _knob("TOCVP_ATTN_QK", "f16x3") != "fp32"
 
 
+# sequence lengths of 128 n + 1 (ViT: patches + class token): last query row in its own launch (TOCVP_MHA_TAIL_ROW=0: off)
+_MHA_TAIL_ROW = os.environ.get("TOCVP_MHA_TAIL_ROW", "1") != "0"
+
+
 def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     """
     q: (B, Tq, E) view with unit last stride (may be a column slice of a fused projection);
@@ -977,6 +989,18 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
     if _ATTN_QK16 and _CHECK_RANGE:
         _check_f16_range(max(absmax(q), absmax(k), absmax(v)),
                          "attention q / k / v (f16x3 products)", owner=("kernels", "_ATTN_QK16"))
+    if _ATTN_QK16 and _MHA_TAIL_ROW and Tq > 128 and Tq % 128 == 1 and Tk <= 1024 and B * heads >= 256:
+        # one row past a multiple of the 128-query tile (256 patches + class token): the tile kernel on the first Tq - 1
+        # rows, the last row on its own (a third tile would stage every key and value again for that one row)
+        def two():
+            _check(lib().tocvp_mha_qk16_rows_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E,
+                                                 B, heads, Tq, Tq - 1, Tk, dh, float(scale), _ptr(key_len), _stream()),
+                   "tocvp_mha_qk16_rows_f32")
+            _check(lib().tocvp_mha_one_query_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E,
+                                                 B, heads, Tq, Tq - 1, Tk, dh, float(scale), _ptr(key_len), _stream()),
+                   "tocvp_mha_one_query_f32")
+        _timed(lambda: f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, two)
+        return o
     fn = lib().tocvp_mha_qk16_f32 if _ATTN_QK16 else lib().tocvp_mha_f32
     _timed(lambda: f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, lambda: _check(
         fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
