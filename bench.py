@@ -262,11 +262,13 @@ def arithmetic_string(savi, pred, kernels):
             f"QK^T and PV {attn}; slot-attention iteration, softmax, LayerNorm, GRU exact fp32")
 
 
-def leg_config4(dev, kernels, batch=16, reps=2):
+def leg_config4(dev, kernels, batch=64, reps=2):
     """
     BASELINE configs[3] on the driver's clock (reference 05_evaluate_predictor.py:53-104 on
     configs/models/ExtendedDINOSAUR.json): ExtendedDINOSAUR FROM PIXELS (DINOv2 ViT-B/14 backbone, 24 slots,
-    224x224 -> 256 patches) + TextOCVP_T5, 1 seed + 29 preds, ``batch`` sequences; one warm-up, ``reps`` timed
+    224x224 -> 256 patches) + TextOCVP_T5, 1 seed + 29 preds, ``batch`` sequences (64 since the end of round 4: the rollout
+    of 16 sequences is a chain of short kernels on 384 tokens per frame that neither fills the chip nor hides under the
+    decoder -- 2053 / 2258 / 2344 frames/s at 16 / 32 / 64 sequences on one box); one warm-up, ``reps`` timed
     passes (median).  Roofline: the split-fp16 GEMM shape with the largest total time (ViT / MLP decoder /
     predictor), HIP events of the last timed pass.
     """
