@@ -28,7 +28,7 @@ constexpr int LS = BK + 4;  // padded LDS row stride (floats)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == TOCVP_ACT_GELU) return tocvp_gelu(v);
     return v;
 }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x4 with_r4(f32x4 v, f32x4 r, int act) {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == TOCVP_ACT_GELU) return tocvp_gelu(v);
     return v;
 }
 
@@ -66,7 +66,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // carried a ladder of scalar branches (and the inlined erff of the GELU it did not take)
 template <int ACT> __device__ __forceinline__ float apply_act_c(float v) {
     if constexpr (ACT == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
-    else if constexpr (ACT == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    else if constexpr (ACT == TOCVP_ACT_GELU) return tocvp_gelu(v);
     else return v;
 }
 template <int ACT> __device__ __forceinline__ f32x4 with_r4_c(f32x4 v, f32x4 r) {

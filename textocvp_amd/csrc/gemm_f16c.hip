@@ -85,7 +85,7 @@ __device__ __forceinline__ void weave() {
 
 __device__ __forceinline__ float act_of(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == TOCVP_ACT_GELU) return tocvp_gelu(v);
     return v;
 }
 

@@ -68,7 +68,7 @@ struct PArgs {
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == TOCVP_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == TOCVP_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == TOCVP_ACT_GELU) return tocvp_gelu(v);
     return v;
 }
 
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_planes3_kernel(PArgs p, int n
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const float x = acc[i][j][4 * q + u] * (1.f / (SA * SW)) + bq[q][u];
-                            v[u] = GELU ? 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)) : fmaxf(x, act_floor);
+                            v[u] = GELU ? tocvp_gelu(x) : fmaxf(x, act_floor);
                         }
                         if (HASR) v += rq[q];
 #if defined(TOCVP_P3_STORE) && TOCVP_P3_STORE == 0
