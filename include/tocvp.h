@@ -82,7 +82,9 @@ int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsplit, int ns
 
 /* Variant with the weight stored in MFMA-fragment order Wf[n/32][k/16][plane][lane] (16 B per lane,
  * tocvp_split_weights_frag_bf16): B fragments are fetched straight from L2 with coalesced 1 KiB
- * loads and never pass through LDS.  Requires K % 64 == 0 and N % 32 == 0. */
+ * loads and never pass through LDS.  Requires K % 64 == 0 and N % 32 == 0.  With a_split (A given as operand
+ * planes (M, planes, K)) one call takes at most 2^32 bytes of planes (32-bit byte offsets; TOCVP_EINVAL beyond: cut
+ * the rows). */
 int tocvp_split_weights_frag_bf16(const float* w, void* out, int N, int K, int nsplit, void* stream);
 int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wfrag, int nsplit,
                              const float* bias, const float* R, int ldr,

@@ -1128,3 +1128,43 @@ def test_mha_tail_row_of_the_vit_sequence_length(B, H, T, dh, monkeypatch):
                                       dh ** -0.5, kl.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert (o2[:, 5].cpu() - ref[:, 5]).abs().max().item() < 3e-6 and float(o2[:, 6].abs().max()) == 0.0
+
+
+def test_plane_input_gemms_beyond_four_gigabytes_of_planes(monkeypatch):
+    """
+    The plane-input kernels address their A operand with 32-bit byte offsets (LDS-DMA sources).  More than 2^32 bytes of
+    planes (here 263 000 rows at K = 4096; configs[3] decoded in one call hands 2.85 M rows of 1024 to the MLPPatchDecoder's
+    layers) must go through in row blocks: every path (chunk-resident, mid-size, two-operand) against float64 on rows before,
+    around and behind the limit, and bit-identical to one another.  (Before round 4's guard the two-operand planes kernel
+    returned wrong rows behind the limit, silently.)
+    """
+    k = _k()
+    M, N, Kd = 263_000, 512, 4096
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    x = torch.randn(M, Kd, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    v = torch.clamp(x * 256.0, -65504.0, 65504.0)
+    hi = v.to(torch.float16)
+    planes = torch.empty(M, 2, Kd, device=DEV, dtype=torch.float16)
+    planes[:, 0], planes[:, 1] = hi, (v - hi.float()).to(torch.float16)
+    del v, hi
+    xp = k.SplitAct(planes, (M, Kd))
+    assert planes.numel() * 2 > 2 ** 32
+    outs = {}
+    with k.gemm_precision("f16x3"):
+        for name, chunk, mid in (("chunk", True, False), ("two-operand", False, False)):
+            monkeypatch.setattr(k, "_GEMM_CHUNK", chunk)
+            monkeypatch.setattr(k, "_GEMM_MID", mid)
+            outs[name] = k.linear(xp, w, b, act=k.ACT_RELU)
+        monkeypatch.setattr(k, "_GEMM_CHUNK", False)
+        pl = k.linear(xp, w, b, act=k.ACT_RELU, out_split=22)
+    limit = 2 ** 32 // (4 * Kd)
+    for rows in (slice(0, 256), slice(limit - 128, limit + 128), slice(M - 256, M)):
+        ref = torch.relu(x[rows].double() @ w.double().t() + b.double())
+        for name, o in outs.items():
+            err = (o[rows].double() - ref).abs().max().item()
+            assert err < 1e-5 * max(1.0, ref.abs().max().item()), (name, rows, err)
+        rebuilt = pl.planes[rows].double().sum(dim=1) / 256.0
+        assert (rebuilt - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs["chunk"], outs["two-operand"])

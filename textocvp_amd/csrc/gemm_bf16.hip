@@ -999,6 +999,8 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
     TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3 || nsplit == 22);
     TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0);
     TOCVP_CHECK_ARG(a_split || lda >= K);
+    // operand planes are addressed with 32-bit byte offsets: at most 2^32 bytes of planes per call (the caller cuts rows)
+    TOCVP_CHECK_ARG(!a_split || (size_t)M * (nsplit == 22 ? 2 : nsplit) * K * 2 < 0x100000000ull);
     TOCVP_CHECK_ARG(c_split || ldc >= N);
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));

@@ -800,8 +800,23 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
             _check_f16_range(absmax(x2), f"f16x3 GEMM ({M}x{N}x{K}) activation")
         _check_f16_weight_range(w, f"f16x3 GEMM ({N}x{K})")
     bn = 512 if N % 512 == 0 else 384
-    if (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and chunk_ok and rowvec is None and N % bn == 0 and K % 128 == 0 and
-            ((M + 127) // 128) * (N // bn) >= _GEMM_CHUNK_MIN_TILES and act in (ACT_NONE, ACT_RELU, ACT_GELU)):
+    use_chunk = (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and chunk_ok and rowvec is None and N % bn == 0 and
+                 K % 128 == 0 and ((M + 127) // 128) * (N // bn) >= _GEMM_CHUNK_MIN_TILES and
+                 act in (ACT_NONE, ACT_RELU, ACT_GELU))
+    if pre_split and not use_chunk and rowvec is None and M * (4 if nsplit == 22 else 2 * nsplit) * K >= 2 ** 32:
+        # the plane-input kernels address the A operand with 32-bit byte offsets (LDS-DMA sources): more than 2^32 bytes
+        # of planes (1 048 576 rows at K = 1024) go through in row blocks -- found with scripts/probes/gemm_chunk_big_m.py:
+        # rows behind the limit came back wrong, silently
+        step = ((2 ** 32 - 1) // ((4 if nsplit == 22 else 2 * nsplit) * K)) // 128 * 128
+        for r0 in range(0, M, step):
+            mb = min(step, M - r0)
+            sub = linear(SplitAct(x2[r0:r0 + mb], (mb, K)), weight, bias, act=act,
+                         residual=None if r2 is None else r2[r0:r0 + mb], precision=precision, out_split=out_split,
+                         chunk_ok=chunk_ok, out=None if out_split else out[r0:r0 + mb])
+            if out_split:
+                out[r0:r0 + mb].copy_(sub.planes)
+        return SplitAct(out, (*lead, N)) if out_split else out.reshape(*lead, N)
+    if use_chunk:
         # A chunks resident in LDS, weights streamed in fragment order (gemm_f16c.hip); 32-bit DMA offsets: row blocks
         ws = _split_weight(w, 22, frag=True)
         step = ((2 ** 32 - 1) // (4 * K)) // 128 * 128
