@@ -1168,3 +1168,24 @@ def test_plane_input_gemms_beyond_four_gigabytes_of_planes(monkeypatch):
         rebuilt = pl.planes[rows].double().sum(dim=1) / 256.0
         assert (rebuilt - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
     assert torch.equal(outs["chunk"], outs["two-operand"])
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
+def test_fp32_input_split_gemms_beyond_four_gigabytes_of_activations(prec):
+    """
+    1 100 003 rows x 1024 fp32 activations (4.5 GB; configs[3] decoded in ONE call hands the MLPPatchDecoder 2.85 M such
+    rows, reference 05_evaluate_predictor.py:88-96): the split kernels' 32-bit byte offsets wrapped behind 2^32 bytes and
+    rows >= 1 048 576 came back wrong in rounds 1-3 -- kernels.linear cuts the rows into blocks now.  Against float64 on
+    rows before, around and behind the line.
+    """
+    k = _k()
+    M, N, Kd = 1_100_003, 256, 1024
+    x = torch.randn(M, Kd, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    g = torch.Generator().manual_seed(9)
+    w, b = (torch.randn(N, Kd, generator=g) / 32).to(DEV), torch.randn(N, generator=g).to(DEV)
+    with k.gemm_precision(prec):
+        y = k.linear(x, w, b, act=k.ACT_RELU)
+    tol = 2e-5 if prec == "f16x3" else 2e-4
+    for rows in (slice(0, 256), slice(1048576 - 128, 1048576 + 128), slice(M - 256, M)):
+        ref = torch.relu(x[rows].double() @ w.double().t() + b.double())
+        assert (y[rows].double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), rows

@@ -853,3 +853,29 @@ def test_config4_plane_handovers_and_chunk_gemm_are_bit_identical(monkeypatch):
     assert any(n == "gemm_split22_16448x2304x768" for n in names) and any(n == "gemm_split22_16448x768x3072" for n in names)
     for a, b, what in zip(ref, got, ("recons_feats", "masks", "recons_imgs", "vit tokens")):
         assert torch.equal(a, b), what
+
+
+@pytest.mark.parametrize("planes", [True, False])
+@torch.no_grad()
+def test_dinosaur_decode_of_many_frames_in_one_call(planes, monkeypatch):
+    """
+    The reference's evaluator decodes ALL predicted frames in one call (05_evaluate_predictor.py:88-96).  For configs[3]
+    that hands the MLPPatchDecoder more than 2^32 bytes of activations per layer (here 200 frames x 24 slots x 256 patches =
+    1 228 800 rows of 1024): the split GEMMs' 32-bit operand offsets wrapped behind the 4 GB line until the end of round 4
+    (rows >= 1 048 576 wrong, silently).  One call must equal the same frames decoded eight at a time, bit for bit, with
+    plane hand-overs (chunk-resident GEMM) and with fp32 hand-overs (two-operand kernels).
+    """
+    from textocvp_amd import kernels as K
+    from textocvp_amd.setup_model import default_dinosaur_params
+    from textocvp_amd.models.EncodersDecoders import decoders as D
+    monkeypatch.setattr(D, "_MLP_PLANES", planes)
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224)).eval()
+    synth.fill_module_(model, prefix="dino.")
+    model = model.to(DEV)
+    model.decoder.reconstruct_images = False                        # the MLP + compositing (the image head is per frame)
+    slots = gpu(synth.synth_noise(200, 24, 128, seed=13))
+    one = model(mode="decode", slots=slots)
+    for lo in (0, 96, 168, 192):                                    # frames before, across and behind the 4 GB line
+        part = model(mode="decode", slots=slots[lo:lo + 8].contiguous())
+        assert torch.equal(one["recons_feats"][lo:lo + 8], part["recons_feats"]), lo
+        assert torch.equal(one["masks"][lo:lo + 8], part["masks"]), lo

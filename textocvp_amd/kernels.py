@@ -803,6 +803,21 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
     use_chunk = (frag_ok and pre_split and nsplit == 22 and _GEMM_CHUNK and chunk_ok and rowvec is None and N % bn == 0 and
                  K % 128 == 0 and ((M + 127) // 128) * (N // bn) >= _GEMM_CHUNK_MIN_TILES and
                  act in (ACT_NONE, ACT_RELU, ACT_GELU))
+    if not pre_split and nsplit and M * 4 * K >= 2 ** 32:
+        # the split kernels address A with 32-bit byte offsets as well: more than 2^32 bytes of fp32 activations (1 048 576
+        # rows at K = 1024 -- configs[3] decoded in ONE call, as the reference's evaluator does, hands the MLPPatchDecoder
+        # 2.85 M rows) came back wrong behind the limit in rounds 1-3, silently (scripts/probes/gemm_big_m_fp32.py; the
+        # exact-fp32 kernel is not affected): row blocks
+        if rowvec is not None:
+            raise TocvpError("linear: a row-periodic vector with more than 2^32 bytes of activations is not supported")
+        step = ((2 ** 32 - 1) // (4 * K)) // 128 * 128
+        for r0 in range(0, M, step):
+            mb = min(step, M - r0)
+            sub = linear(x2[r0:r0 + mb], weight, bias, act=act, residual=None if r2 is None else r2[r0:r0 + mb],
+                         precision=precision, out_split=out_split, chunk_ok=chunk_ok, out=None if out_split else out[r0:r0 + mb])
+            if out_split:
+                out[r0:r0 + mb].copy_(sub.planes)
+        return SplitAct(out, (*lead, N)) if out_split else out.reshape(*lead, N)
     if pre_split and not use_chunk and rowvec is None and M * (4 if nsplit == 22 else 2 * nsplit) * K >= 2 ** 32:
         # the plane-input kernels address the A operand with 32-bit byte offsets (LDS-DMA sources): more than 2^32 bytes
         # of planes (1 048 576 rows at K = 1024) go through in row blocks -- found with scripts/probes/gemm_chunk_big_m.py:
