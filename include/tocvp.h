@@ -229,6 +229,14 @@ int tocvp_mha_qk16_rows_f32(const float* Q, int ldq, const float* K, int ldk, co
 int tocvp_mha_one_query_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                             int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale, const int32_t* key_len,
                             void* stream);
+/* the two entries above with O written as fp16 operand planes (B * Tq_total, 2, H*dh) of 2^8 O for a following plane-input
+ * GEMM (the ViT's attention output projection, timm_encoders.py:59-70): both products stay on the f16 matrix cores */
+int tocvp_mha_qk16_rows_split_f16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Osplit,
+                                  int B, int H, int Tq_total, int q_rows, int Tk, int dh, float scale,
+                                  const int32_t* key_len, void* stream);
+int tocvp_mha_one_query_split_f16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Osplit,
+                                  int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale, const int32_t* key_len,
+                                  void* stream);
 /* same, O written as operand planes: (B*Tq, nsplit, H*dh) bf16 (nsplit 2 or 3) or, nsplit 22,
  * (B*Tq, 2, H*dh) fp16 planes of 2^8 O */
 int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

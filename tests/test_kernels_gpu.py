@@ -1121,6 +1121,12 @@ def test_mha_tail_row_of_the_vit_sequence_length(B, H, T, dh, monkeypatch):
     close(one, ref)
     assert torch.equal(got[:, :T - 1], one[:, :T - 1]), "the first T - 1 rows come from the same tile kernel"
     assert (got[:, T - 1] - one[:, T - 1]).abs().max().item() < 3e-6
+    # O as fp16 operand planes (tocvp_mha_qk16_rows_split_f16 + tocvp_mha_one_query_split_f16): the split of the fp32 output
+    monkeypatch.setattr(k, "_MHA_TAIL_ROW", True)
+    pl = k.mha(d[..., :E], d[..., E:2 * E], d[..., 2 * E:], H, dh ** -0.5, key_len=kl, out_split=22)
+    v_ = torch.clamp(got * 256.0, -65504.0, 65504.0).reshape(B * T, E)
+    hi_ = v_.to(torch.float16)
+    assert torch.equal(pl.planes[:, 0], hi_) and torch.equal(pl.planes[:, 1], (v_ - hi_.float()).to(torch.float16))
     # direct C-ABI call of the one-row kernel on another row, plain (B, T, E) tensors
     q2, k2, v2 = (t.contiguous() for t in (d[..., :E], d[..., E:2 * E], d[..., 2 * E:]))
     o2 = torch.zeros(B, T, E, device=DEV)

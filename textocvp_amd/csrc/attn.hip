@@ -350,7 +350,18 @@ __global__ __launch_bounds__(256) void mha_one_query_kernel(MhaArgs p, int q_row
             a3 = fmaf(ps[wave][j + 3], Vb[(size_t)(j + 3) * p.ldv + lane], a3);
         }
         for (; j < kv_len; ++j) a0 = fmaf(ps[wave][j], Vb[(size_t)j * p.ldv + lane], a0);
-        p.O[((size_t)b * p.TqTot + q_row) * p.ldo + head * DH + lane] = ((a0 + a1) + (a2 + a3)) / sum;
+        const float o = ((a0 + a1) + (a2 + a3)) / sum;
+        if (p.Osplit == nullptr) {
+            p.O[((size_t)b * p.TqTot + q_row) * p.ldo + head * DH + lane] = o;
+        } else {
+            // fp16 operand planes of 2^8 o (the expressions of tocvp_store_planes4, one element per lane)
+            const int E = p.H * DH;
+            const float X = __builtin_amdgcn_fmed3f(o * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
+            const _Float16 hi = (_Float16)X;
+            _Float16* dst = static_cast<_Float16*>(p.Osplit) + ((size_t)b * p.TqTot + q_row) * 2 * E + head * DH + lane;
+            dst[0] = hi;
+            dst[E] = (_Float16)(X - (float)hi);
+        }
     }
 }
 
@@ -421,16 +432,42 @@ extern "C" int tocvp_mha_qk16_rows_f32(const float* Q, int ldq, const float* K, 
                       Tq_total);
 }
 
+static int tocvp_mha_one_query_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                   void* Osplit, int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale,
+                                   const int32_t* key_len, void* stream);
+
+extern "C" int tocvp_mha_qk16_rows_split_f16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                             void* Osplit, int B, int H, int Tq_total, int q_rows, int Tk, int dh,
+                                             float scale, const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Osplit != nullptr && q_rows > 0 && q_rows <= Tq_total);
+    return mha_launch(Q, ldq, K, ldk, V, ldv, nullptr, 0, Osplit, 22, B, H, q_rows, Tk, dh, scale, key_len, stream, nullptr,
+                      true, Tq_total);
+}
+
 extern "C" int tocvp_mha_one_query_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                        int ldo, int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale,
                                        const int32_t* key_len, void* stream) {
-    TOCVP_CHECK_ARG(Q && K && V && O);
+    return tocvp_mha_one_query_out(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, B, H, Tq_total, q_row, Tk, dh, scale, key_len, stream);
+}
+
+extern "C" int tocvp_mha_one_query_split_f16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                             void* Osplit, int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale,
+                                             const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Osplit != nullptr);
+    return tocvp_mha_one_query_out(Q, ldq, K, ldk, V, ldv, nullptr, H * dh, Osplit, B, H, Tq_total, q_row, Tk, dh, scale, key_len,
+                                   stream);
+}
+
+static int tocvp_mha_one_query_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                   void* Osplit, int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale,
+                                   const int32_t* key_len, void* stream) {
+    TOCVP_CHECK_ARG(Q && K && V && (O || Osplit));
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq_total > 0 && q_row >= 0 && q_row < Tq_total && Tk > 0 && Tk <= ONEQ_MAXK);
     TOCVP_CHECK_ARG(dh == 32 || dh == 64);
     TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh);
     if ((ldk & 3) || !tocvp_aligned16(K)) return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
-    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, 1, Tk, scale, key_len, nullptr, 0, nullptr, 0, Tq_total};
+    MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, 1, Tk, scale, key_len, Osplit, Osplit ? 22 : 0, nullptr, 0, Tq_total};
     const dim3 grid((unsigned)(((long)B * H + 3) / 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dh == 64) hipLaunchKernelGGL(mha_one_query_kernel<64>, grid, dim3(256), 0, s, p, q_row);

@@ -97,6 +97,14 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
         ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_mha_qk16_rows_split_f16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_mha_one_query_split_f16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -1008,6 +1016,21 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
                                         v.stride(1), _ptr(o), E, B, heads, Tq, Tk, dh, float(scale),
                                         _ptr(key_len), _ptr(bias), _stream()), "tocvp_mha_bias_f32")
         return o
+    if out_split == 22 and _ATTN_QK16 and not _CHECK_RANGE:
+        # both products on the f16 matrix cores, O as fp16 operand planes (the split the consuming GEMM would make)
+        o = _alloc_planes(B * Tq, 22, E, q.device)
+        tail = _MHA_TAIL_ROW and Tq > 128 and Tq % 128 == 1 and Tk <= 1024 and B * heads >= 256
+
+        def planes_out():
+            _check(lib().tocvp_mha_qk16_rows_split_f16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1),
+                                                       _ptr(o), B, heads, Tq, Tq - 1 if tail else Tq, Tk, dh, float(scale),
+                                                       _ptr(key_len), _stream()), "tocvp_mha_qk16_rows_split_f16")
+            if tail:
+                _check(lib().tocvp_mha_one_query_split_f16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1),
+                                                           _ptr(o), B, heads, Tq, Tq - 1, Tk, dh, float(scale),
+                                                           _ptr(key_len), _stream()), "tocvp_mha_one_query_split_f16")
+        _timed(lambda: f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, planes_out)
+        return SplitAct(o, (B, Tq, E))
     if out_split:
         o = _alloc_planes(B * Tq, out_split, E, q.device)
         _check(lib().tocvp_mha_split_bf16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v),

@@ -198,7 +198,7 @@ class ViTEncoder(nn.Module):
                 y = K.layer_norm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, split=ns)
                 qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
                 a = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], blk.attn.num_heads,
-                          (E // blk.attn.num_heads) ** -0.5)
+                          (E // blk.attn.num_heads) ** -0.5, out_split=ns if K._ATTN_QK16 else 0)
                 w, b = self._scaled(("proj", i), blk.attn.proj, blk.ls1)
                 x = K.linear(a, w, b, residual=x)
                 y = K.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, split=ns)
