@@ -879,3 +879,37 @@ def test_dinosaur_decode_of_many_frames_in_one_call(planes, monkeypatch):
         part = model(mode="decode", slots=slots[lo:lo + 8].contiguous())
         assert torch.equal(one["recons_feats"][lo:lo + 8], part["recons_feats"]), lo
         assert torch.equal(one["masks"][lo:lo + 8], part["masks"]), lo
+
+
+@torch.no_grad()
+def test_dinosaur_reference_default_resolution_336():
+    """
+    The reference's shipped ExtendedDINOSAUR config is 336 x 336 (configs/models/ExtendedDINOSAUR.json:2,26: 576 patches, a
+    24 x 24 grid, 577 ViT tokens); BASELINE configs[3] and every other test run 224 x 224.  Here: the MLPPatchDecoder + image
+    head (24-wide layers: regular conv tiles, phase convolutions, bilinear resize to 336) and the ViT on one frame against
+    the oracle, and a small end-to-end evaluation (10 slots, 1 seed + 3 preds) for shapes and finiteness.
+    """
+    from textocvp_amd.setup_model import default_dinosaur_params
+    S, Kk, P, B = 336, 10, 3, 2
+    model = setup_model(default_dinosaur_params(num_slots=Kk, img_size=S)).eval()
+    exp = default_exp_params(num_slots=Kk, num_context=1, num_preds=P, predictor_name="TextOCVP_T5")
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(model, prefix="dino.")
+    synth.fill_module_(pred, prefix="pred.")
+    sd = {k_: v.clone() for k_, v in model.state_dict().items()}
+    model, pred = model.to(DEV), pred.to(DEV)
+    videos = gpu(synth.synth_videos(B, 1 + P, height=S, width=S, seed=4))
+    ids = torch.randint(1, 32000, (B, 9), generator=torch.Generator().manual_seed(2)).to(DEV)
+    mask = torch.ones(B, 9, dtype=torch.int64, device=DEV)
+    noise = synth.synth_noise(B, Kk, 128, seed=3)
+    out = forward_eval(model, pred, videos, 1, P, caption_tokens=ids, attn_masks=mask, init_noise=gpu(noise))
+    assert out["pred_imgs"].shape == (B, P, 3, S, S) and out["masks"].shape == (B * P, Kk, 1, 24, 24)
+    assert all(bool(torch.isfinite(v).all()) for v in out.values() if torch.is_tensor(v) and v.numel())
+    slots = out["pred_slots"][0, :1].contiguous()
+    dec = model(mode="decode", slots=slots)
+    ref_imgs, ref_feats, _ = O.mlp_patch_decoder(O.sub(sd, "decoder."), slots.cpu(), img_size=S)
+    assert max_abs(dec["recons_feats"].cpu(), ref_feats) < 2e-4 and max_abs(dec["recons_imgs"].cpu(), ref_imgs) < 5e-6
+    ref_tok = O.vit_encoder(O.sub(sd, "encoder.vit_backbone."), videos[0, :1].cpu())
+    got_tok = model.encoder(videos[0, :1])
+    assert got_tok.shape == (1, 576, 768)
+    assert max_abs(got_tok.cpu(), ref_tok) < 2e-5 * max(1.0, float(ref_tok.abs().max()))
