@@ -783,19 +783,25 @@ def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
 
 
 @pytest.mark.parametrize("B,Tq,Lt", [(3, 300, 12), (2, 37, 5), (1, 30, 16), (61, 270, 12), (130, 140, 9),
-                                     (2, 70, 17), (3, 300, 24), (40, 290, 32), (130, 100, 29)])
-def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt):
+                                     (2, 70, 17), (3, 300, 24), (40, 290, 32), (130, 100, 29),
+                                     (2, 70, 33), (3, 300, 40), (40, 290, 50), (5, 37, 64)])
+def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt, monkeypatch):
     """
     csrc/xattn.hip: LayerNorm + q projection + attention over the caption + output projection + residual in ONE
     kernel, with the projections folded into per-sample caption operands.  Against (a) an fp64 evaluation of the
     reference's TransformerDecoderBlock cross-attention half (attention.py:445-463, 303-319) and (b) this repo's
     four-kernel path on the same module (TextKV without collapsed operands); ragged Tq, Lt < 16 (masked slots).
-    Captions of 17-32 tokens (round 4) take 32 caption slots per head (xattn_collapsed_kernel<32>, any batch size).
+    Captions of 17-32 tokens (round 4) take 32 caption slots per head (xattn_collapsed_kernel<32>, any batch size),
+    33-64 tokens (the text encoder admits 50, text_encoders.py:36) 64 slots per head (xattn_collapsed_kernel<64>: two
+    score tiles per head and wave, one workgroup per CU).
     The last two shapes fill the chip and take the 64-token-workgroup variant (B not a multiple of 8: idle ids of the
     XCD-aware numbering; Tq not a multiple of 64), the first three the 32-token variant.
     """
+    from textocvp_amd.models.Blocks import attention as A
     from textocvp_amd.models.Blocks.attention import TextKV, TransformerDecoderBlock
     k = _k()
+    if Lt > 32:                                                    # the 64-slot form is opt-in (TOCVP_XATTN_MAX_LT=64)
+        monkeypatch.setattr(A, "_XATTN_MAX_LT", 64)
     E, H, dh = 512, 8, 64
     blk = TransformerDecoderBlock(embed_dim=E, head_dim=dh, kv_dim=E, num_heads=H, mlp_size=2048).eval()
     with torch.no_grad():
@@ -836,8 +842,10 @@ def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt):
     assert err < 5e-6 * max(1.0, float(z_ref.abs().max())) and err < 3 * err4 + 2e-6
     assert (full - full4).abs().max().item() < 2e-5
     assert torch.isfinite(z).all()
-    # captions longer than 32 tokens (the text encoder admits 50) fall back to the four-kernel path
+    # captions behind the limit fall back to the four-kernel path (default limit 32: the 64-slot form is opt-in)
     with torch.no_grad(), k.gemm_precision("f16x3"):
+        assert blk.project_text(rnd("xa.long", (B, 65, E), "normal").to(DEV)).collapsed is None
+        monkeypatch.setattr(A, "_XATTN_MAX_LT", 32)
         assert blk.project_text(rnd("xa.long", (B, 33, E), "normal").to(DEV)).collapsed is None
 
 

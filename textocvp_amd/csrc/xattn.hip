@@ -54,11 +54,15 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
 
 // 8 waves, 64 tokens of one sample.  34 KB of LDS and ~100 registers: four workgroups (32 waves) per CU -- the kernel
 // is a chain of short dependent phases, what hides their latency is other workgroups.
+// LPT = 64 (round 4, captions of 33-50 tokens -- the text encoder admits 50, text_encoders.py:36): 64 caption slots per
+// head = the uncollapsed width (no FLOP saving), but still ONE kernel instead of LayerNorm + q GEMM + attention + output
+// GEMM; a wave owns the TWO 32-row score tiles of its head, the P image takes 132 KB of LDS (one workgroup per CU).
 template <int LPT>
-__global__ __launch_bounds__(512, LPT == 16 ? 6 : 4) void xattn_collapsed_kernel(XArgs p, int gx) {
+__global__ __launch_bounds__(512, LPT == 16 ? 6 : (LPT == 32 ? 4 : 2)) void xattn_collapsed_kernel(XArgs p, int gx) {
     constexpr int NPT = HEADS * LPT;                                 // padded score columns
     constexpr int PROWT = 2 * NPT * 2 + 16;                          // P image row: [plane][n] + 16 B pad
     constexpr int NMB = LPT == 16 ? 1 : 2;                           // token blocks per wave in phase 1
+    constexpr int NSB = LPT == 64 ? 2 : 1;                           // 32-row score tiles per wave in phase 1
     __shared__ __attribute__((aligned(16))) unsigned char lds[TOK * (PROWT > XROW ? PROWT : XROW)];
     __shared__ float stats[TOK * 2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -102,13 +106,17 @@ __global__ __launch_bounds__(512, LPT == 16 ? 6 : 4) void xattn_collapsed_kernel
     // ---- phase 1: S^T = G LN(x)^T, LN(x) staged in chunks of 128 columns as fp16 operand planes.
     // LPT = 16: wave -> score rows n = 32 (wave & 3) + .. (heads 2 (wave & 3), + 1), tokens m = 32 (wave >> 2) + ..
     // LPT = 32: wave -> the 32 caption slots of head `wave`, both token blocks (one G fragment feeds two products)
-    const int nb = LPT == 16 ? (wave & 3) : wave, mb0 = LPT == 16 ? (wave >> 2) : 0;
-    f32x16 sacc[NMB];
+    // LPT = 64: wave -> the 64 caption slots of head `wave` = score row blocks 2 wave, 2 wave + 1, both token blocks
+    const int nb = LPT == 16 ? (wave & 3) : (LPT == 32 ? wave : 2 * wave), mb0 = LPT == 16 ? (wave >> 2) : 0;
+    f32x16 sacc[NSB][NMB];
 #pragma unroll
-    for (int i = 0; i < NMB; ++i)
+    for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+        for (int i = 0; i < NMB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[sb][i][r] = 0.f;
     const f16x8* gf = reinterpret_cast<const f16x8*>(p.Gf) + ((size_t)(b * (NPT / 32) + nb) * (E / 16) * 2) * 64 + lane;
+    constexpr size_t GBLK = (size_t)(E / 16) * 2 * 64;               // f16x8 elements per 32-row block of G
     const unsigned char* xl = lds + (32 * mb0 + l31) * XROW + hh * 16;
 #pragma unroll 1
     for (int ch = 0; ch < E / KC; ++ch) {
@@ -135,66 +143,82 @@ __global__ __launch_bounds__(512, LPT == 16 ? 6 : 4) void xattn_collapsed_kernel
         __syncthreads();
 #pragma unroll 2
         for (int ks = 0; ks < KC / 16; ++ks) {
-            const f16x8 wh = gf[(size_t)(ch * (KC / 16) + ks) * 128];
-            const f16x8 wl = gf[(size_t)(ch * (KC / 16) + ks) * 128 + 64];
+            f16x8 wh[NSB], wl[NSB];
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+                wh[sb] = gf[sb * GBLK + (size_t)(ch * (KC / 16) + ks) * 128];
+                wl[sb] = gf[sb * GBLK + (size_t)(ch * (KC / 16) + ks) * 128 + 64];
+            }
 #pragma unroll
             for (int i = 0; i < NMB; ++i) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(xl + i * 32 * XROW + ks * 32);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(xl + i * 32 * XROW + KC * 2 + ks * 32);
-                sacc[i] = mfma16(wh, al, sacc[i]);
-                sacc[i] = mfma16(wl, ah, sacc[i]);
-                sacc[i] = mfma16(wh, ah, sacc[i]);
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) {
+                    sacc[sb][i] = mfma16(wh[sb], al, sacc[sb][i]);
+                    sacc[sb][i] = mfma16(wl[sb], ah, sacc[sb][i]);
+                    sacc[sb][i] = mfma16(wh[sb], ah, sacc[sb][i]);
+                }
             }
         }
     }
     // softmax over the caption slots of each head.  Register r of lane half hh = score row (r & 3) + 8 (r >> 2) + 4 hh
     // of the tile; the other half of the rows sits in lane ^ 32.  LPT = 16: rows 0-15 / 16-31 = heads 2 nb / 2 nb + 1
     // (registers 0-7 / 8-15); LPT = 32: the tile is one head
-    float pr[NMB][16];
-    constexpr int NG = 32 / LPT, RG = 16 / NG;        // heads per tile, registers per head and lane
+    // (LPT = 64: the head's slots are rows 0-31 of tile sb = 0 and of tile sb = 1: slot 32 sb + row)
+    float pr[NSB][NMB][16];
+    constexpr int NG = LPT >= 32 ? 1 : 2, RG = 16 / NG;   // heads per tile, registers per head, tile and lane
 #pragma unroll
     for (int i = 0; i < NMB; ++i)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             float mx = -3.0e38f;
 #pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
-                const float sv = sacc[i][RG * g + q] * p.scale;
-                pr[i][RG * g + q] = sv;
-                if (tt < p.Lt) mx = fmaxf(mx, sv);
-            }
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const int tt = 32 * sb + 4 * hh + (q & 3) + 8 * (q >> 2);
+                    const float sv = sacc[sb][i][RG * g + q] * p.scale;
+                    pr[sb][i][RG * g + q] = sv;
+                    if (tt < p.Lt) mx = fmaxf(mx, sv);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                const int tt = 4 * hh + (q & 3) + 8 * (q >> 2);
-                const float e = tt < p.Lt ? expf(pr[i][RG * g + q] - mx) : 0.f;
-                pr[i][RG * g + q] = e;
-                sum += e;
-            }
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const int tt = 32 * sb + 4 * hh + (q & 3) + 8 * (q >> 2);
+                    const float e = tt < p.Lt ? expf(pr[sb][i][RG * g + q] - mx) : 0.f;
+                    pr[sb][i][RG * g + q] = e;
+                    sum += e;
+                }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int q = 0; q < RG; ++q) pr[i][RG * g + q] *= inv;
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int q = 0; q < RG; ++q) pr[sb][i][RG * g + q] *= inv;
         }
     __syncthreads();                                  // every wave has finished reading the LN image
-    // P as operand planes: row m = 32 (mb0 + i) + l31, column n = 32 nb + 8 u + 4 hh + {0..3} for register quad u
+    // P as operand planes: row m = 32 (mb0 + i) + l31, column n = 32 (nb + sb) + 8 u + 4 hh + {0..3} for register quad u
 #pragma unroll
-    for (int i = 0; i < NMB; ++i)
+    for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            f16x4 hi, lo;
+        for (int i = 0; i < NMB; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float sc = pr[i][4 * u + e] * SA;
-                hi[e] = (_Float16)sc;
-                lo[e] = (_Float16)(sc - (float)hi[e]);
+            for (int u = 0; u < 4; ++u) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = pr[sb][i][4 * u + e] * SA;
+                    hi[e] = (_Float16)sc;
+                    lo[e] = (_Float16)(sc - (float)hi[e]);
+                }
+                const int n = 32 * (nb + sb) + 8 * u + 4 * hh;
+                *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + n * 2) = hi;
+                *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + NPT * 2 + n * 2) = lo;
             }
-            const int n = 32 * nb + 8 * u + 4 * hh;
-            *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + n * 2) = hi;
-            *reinterpret_cast<f16x4*>(lds + (32 * (mb0 + i) + l31) * PROWT + NPT * 2 + n * 2) = lo;
-        }
     __syncthreads();
 
     // ---- phase 2: Y^T tiles of this wave, one 32-column block at a time (keeps the kernel at 3 workgroups per CU):
@@ -439,7 +463,7 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
                                          const void* Gfrag, const void* Hfrag, const float* bias, float* y, int B,
                                          int Tq, int E_, int heads, int Lt, float scale, void* stream) {
     TOCVP_CHECK_ARG(x && gamma && beta && Gfrag && Hfrag && bias && y);
-    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= 2 * LP);
+    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= 4 * LP);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) || !tocvp_aligned16(beta) ||
         !tocvp_aligned16(bias) || !tocvp_aligned16(Gfrag) || !tocvp_aligned16(Hfrag))
         return TOCVP_EALIGN;
@@ -452,6 +476,11 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n;
     }();
+    if (Lt > 2 * LP) {        // 33-64 caption tokens: 64 slots per head
+        hipLaunchKernelGGL(xattn_collapsed_kernel<64>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p, gx);
+        return tocvp_launch_status();
+    }
     if (Lt > LP) {            // 17-32 caption tokens: 32 slots per head (operands built with that padding)
         hipLaunchKernelGGL(xattn_collapsed_kernel<32>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p, gx);

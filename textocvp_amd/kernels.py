@@ -974,8 +974,8 @@ def xattn_collapsed(x, gamma, beta, eps, Gf, Hf, bias, heads, Lt, scale):
     """
     _dev_f32(x, "x")
     B, Tq, E = x.shape
-    LP = 16 if Lt <= 16 else 32                    # caption slots per head the operands were padded to
-    assert x.is_contiguous() and Gf.shape[0] == B * heads * LP and Hf.shape[0] == B * E and Lt <= 32
+    LP = 16 if Lt <= 16 else (32 if Lt <= 32 else 64)   # caption slots per head the operands were padded to
+    assert x.is_contiguous() and Gf.shape[0] == B * heads * LP and Hf.shape[0] == B * E and Lt <= 64
     if _CHECK_RANGE:                               # |LayerNorm(x)| <= sqrt(E) max|gamma| + max|beta|
         _check_f16_range(absmax(gamma) * E ** 0.5 + absmax(beta),
                          "collapsed cross-attention: bound of the LayerNorm output")

@@ -58,6 +58,11 @@ _CHUNK_GEMM = os.environ.get("TOCVP_PREDICTOR_CHUNK_GEMM", "0") != "0"
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
 # LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
 _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
+# longest caption (tokens) the collapsed kernel takes by default.  The 64-slot form for 33-50 tokens (end of round 4:
+# xattn_collapsed_kernel<64>, no FLOP saving any more, one kernel instead of four, one workgroup per CU) is built and
+# tested and measures EQUAL to the four-kernel path at 128 sequences (277-287 vs 280-287 us per block at 40 / 50 tokens;
+# 491-500 vs 546 us at 256) -- opt-in: TOCVP_XATTN_MAX_LT=64
+_XATTN_MAX_LT = int(os.environ.get("TOCVP_XATTN_MAX_LT", "32"))
 
 
 class TextKV:
@@ -336,14 +341,14 @@ class MultiHeadCrossAttention(MetaAttention):
         B, Lt, two_inner = kv.shape
         H, dh, inner = self.num_heads, self.dim_head, two_inner // 2
         E_in, E_out = self.q.weight.shape[1], self.out_projection.weight.shape[0]
-        if not (_XATTN_COLLAPSE and Lt <= 32 and H == 8 and dh == 64 and E_in == 512 and E_out == 512 and
+        if not (_XATTN_COLLAPSE and Lt <= _XATTN_MAX_LT and H == 8 and dh == 64 and E_in == 512 and E_out == 512 and
                 self.out_projection.bias is not None and K.active_nsplit() == 22 and kv.is_contiguous()
                 and B * H <= 65535):
             return None
         # caption slots of a head padded to 16 (captions of at most 16 tokens) or 32 (17-32): with 32 the fused kernel
         # still does half the work of the 512 x 512 projections; 33-50 tokens (text_encoders.py:36 admits 50) would need 64
         # slots per head = the uncollapsed width and keep the four-kernel path
-        LP = 16 if Lt <= 16 else 32
+        LP = 16 if Lt <= 16 else (32 if Lt <= 32 else 64)
         # both operands from ONE batched launch each over (sample, head), slices addressed in place (round 3: 16 small
         # GEMMs + two strided copies, 351 us per block): exact fp32 MFMA, rows / columns behind Lt stay zero
         G = torch.zeros((B, H, LP, E_in), device=kv.device, dtype=torch.float32)
