@@ -810,6 +810,7 @@ def test_textocvp_t5_against_transformers_golden_and_oracle():
     assert max_abs(got.cpu(), torch.stack(ref, dim=1)) < 1e-4
 
 
+@pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32", reason="operand planes exist in the f16x3 arithmetic only")
 @torch.no_grad()
 def test_config4_plane_handovers_and_chunk_gemm_are_bit_identical(monkeypatch):
     """
