@@ -399,6 +399,7 @@ struct MidArgs {
     void* C; int ldc; int c_split;
     int M, N, K, col_tiles, S;
     float* ws_part; unsigned* ws_ctr;
+    int row_tiles, xcd_rows;
 };
 
 template <int ACT, bool CSPLIT, bool HASR>
@@ -407,8 +408,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
     typedef const __attribute__((address_space(1))) f16x8* gv8;
 
-    const int slice = (int)blockIdx.x % p.S, tile = (int)blockIdx.x / p.S;
-    const int rt = tile / p.col_tiles, ct = tile % p.col_tiles;
+    // Workgroup ids are dealt round-robin over the 8 XCDs.  Unsplit launches (xcd_rows): the id's low three bits pick the row
+    // tile inside a group of eight and the column tiles of a row tile follow each other on that XCD, so a row tile's A chunks
+    // come from HBM once (dealt in launch order the eight column tiles of a 2048-wide product landed on eight XCDs and A was
+    // fetched eight times: 173 MB from beyond L2 for 24 MB of operands, PMC of 9600 x 2048 x 512)
+    int slice, tile, rt, ct;
+    if (p.xcd_rows) {
+        const int per_group = 8 * p.col_tiles;
+        const int grp = (int)blockIdx.x / per_group, rem = (int)blockIdx.x % per_group;
+        rt = grp * 8 + (rem & 7);
+        ct = rem >> 3;
+        if (rt >= p.row_tiles) return;
+        slice = 0;
+        tile = rt * p.col_tiles + ct;
+    } else {
+        slice = (int)blockIdx.x % p.S;
+        tile = (int)blockIdx.x / p.S;
+        rt = tile / p.col_tiles;
+        ct = tile % p.col_tiles;
+    }
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -716,8 +734,14 @@ extern "C" int tocvp_gemm_f16mid_f32(const void* A_planes, const void* W_frag, c
     MidArgs p{static_cast<const unsigned char*>(A_planes), static_cast<const unsigned char*>(W_frag), bias, R, ldr, C, ldc,
               c_split, M, N, K, col_tiles, S,
               ws ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + MID_CTR_BYTES) : nullptr,
-              static_cast<unsigned*>(ws)};
-    const dim3 grid((unsigned)(tiles * S));
+              static_cast<unsigned*>(ws), row_tiles, 0};
+    static const bool xcd_on = []() { const char* e = getenv("TOCVP_GEMM_MID_XCD"); return !e || atoi(e) != 0; }();
+    unsigned nwg = (unsigned)(tiles * S);
+    if (S == 1 && xcd_on && col_tiles > 1) {
+        p.xcd_rows = 1;
+        nwg = (unsigned)(((row_tiles + 7) / 8) * 8 * col_tiles);
+    }
+    const dim3 grid(nwg);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define GM_LAUNCH(A_, S_, R_) hipLaunchKernelGGL((gemm_f16x3_mid_kernel<A_, S_, R_>), grid, dim3(256), 0, st, p)
 #define GM_LAUNCH_SR(A_)                                  \
