@@ -483,7 +483,9 @@ _GEMM_MID = os.environ.get("TOCVP_GEMM_MID", "1") != "0"
 # built and deterministic but measured SLOWER than the unsplit launch (2400 x 1536 x 512: 39.7 us with two slices -- the
 # agent-scope release in front of the arrival count), so it is opt-in (TOCVP_GEMM_MID_SPLITK=1)
 _GEMM_MID_MIN_TILES = int(os.environ.get("TOCVP_GEMM_MID_MIN_TILES", "192"))
-_GEMM_MID_MAX_ROWS = int(os.environ.get("TOCVP_GEMM_MID_MAX_ROWS", "16384"))
+# (no upper row limit since the XCD-aware tile order: 38400 x 1536 x 512 188 vs 207 us, 76800 rows 370 vs 393 us against the
+# 256 x 128-tile planes kernel; B = 128 headline 4041 / 4043 vs 4039 / 4040 frames/s, two alternations)
+_GEMM_MID_MAX_ROWS = int(os.environ.get("TOCVP_GEMM_MID_MAX_ROWS", str(1 << 30)))
 _GEMM_MID_SPLITK = os.environ.get("TOCVP_GEMM_MID_SPLITK", "0") != "0"
 _MID_WS = {}
 
