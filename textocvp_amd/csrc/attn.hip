@@ -118,6 +118,8 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
     const int nkb = (kv_len + 31) / 32;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = (QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale) * LOG2E;
     // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
     // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
     constexpr int NITM = (32 * F4 + NT - 1) / NT;                  // items per thread (4 waves): DH 64 -> 2, DH 32 -> 1
@@ -196,35 +198,49 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
             }
         }
 
-        // online softmax over keys: in-lane over 16 regs + the other lane half
+        // online softmax over keys: in-lane over 16 regs + the other lane half.  Scores are kept in the log2 domain
+        // (scale * log2(e) folded into the one multiplication a score gets anyway), so that an exponential is ONE
+        // v_exp_f32 (the library expf is 13 instructions: 220 of the ~650 vector instructions of a tile); the key mask
+        // is applied in the last tile only and the bias branch is taken once per tile, not once per register.
         float bm = NEG_BIG;
+        if (p.bias) {
+            const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
+            const float* brow = p.bias + ((size_t)head * p.Tq + q) * p.Tk;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + acc_row(r, h);
-            float sv = s[r] * (QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale);
-            if (p.bias && key < kv_len) {
-                const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
-                sv += p.bias[((size_t)head * p.Tq + q) * p.Tk + key];
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, h);
+                s[r] = s[r] * sc2 + (key < kv_len ? brow[key] : 0.f) * LOG2E;
             }
-            s[r] = (key < kv_len) ? sv : NEG_BIG;
-            bm = fmaxf(bm, s[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= sc2;
         }
+        if (kb * 32 + 32 > kv_len) {   // wave-uniform: only the last tile holds keys past the end
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (kb * 32 + acc_row(r, h) < kv_len) ? s[r] : NEG_BIG;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
         const float m_new = fmaxf(m_run, bm);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = expf(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
             ps += s[r];
         }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        // the running maximum settles after the first tiles: the accumulators (AGPRs: read, multiply, write back = 83
+        // instructions) are rescaled only when some query of the wave saw a new maximum (alpha = 1 exactly otherwise)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
 
         // O^T (dh x 32 queries) += V^T (dh x keys) * P^T (keys x queries); P^T is `s` as it stands
         if (QK16) {
