@@ -21,4 +21,4 @@ for B, H, T, dh in ((256, 8, 300, 64), (128, 8, 300, 64), (256, 12, 257, 64), (8
     sp = lambda x: x[:nb].double().view(nb, T, H, dh).transpose(1, 2)
     ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dh ** -0.5, -1) @ sp(v)).transpose(1, 2).reshape(nb, T, E)
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"B {B} H {H} T {T} dh {dh}: {us:8.1f} us  {4.0 * B * H * T * T * dh / us * 1e-6:7.1f} TFLOP/s  max err {float((o[:nb].double() - ref).abs().max()):.3e}", flush=True)
+    print(f"B {B} H {H} T {T} dh {dh}: {us:8.1f} us  {4.0 * B * H * T * T * dh / us * 1e-6:7.1f} TFLOP/s  max err {float((o[:nb].double() - ref).abs().max()):.3e}  bits {int(o.view(torch.int32).sum(dtype=torch.int64)):x}", flush=True)

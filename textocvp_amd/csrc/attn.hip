@@ -34,6 +34,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
+// Exponential of the online softmax.  The library expf (13 instructions: 220 of the ~650 vector instructions of a 32-key
+// tile) is the default: with -DTOCVP_MHA_EXP2=1 the scores are kept in the log2 domain (scale x log2 e folded into the
+// score's one multiplication) and an exponential is ONE v_exp_f32 -- as accurate against an fp64 softmax (4.4e-7 vs
+// 4.7e-7 at 256 x 8 x 300 x 300 x 64) and 383 vs 447 us, but other last bits: over a four-step rollout one mask pixel
+// whose two largest masks are 2.2e-6 apart in the oracle goes the other way (tests/test_models_gpu.py::
+// test_e2e_against_oracle_fresh_inputs), so it stays a build-time option.
+#ifndef TOCVP_MHA_EXP2
+#define TOCVP_MHA_EXP2 0
+#endif
+__device__ __forceinline__ float mha_exp(float x) {
+#if TOCVP_MHA_EXP2
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return expf(x);
+#endif
+}
+
 // QK16: BOTH products run on the f16 matrix cores with split operands (hi + lo fp16 planes of 2^8 x, three
 // v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of gemm_bf16.hip Elem<true>, |q|, |k|,
 // |v| < 255): per 32-key tile and 32 queries at dh = 64, 12 + 12 matrix instructions of 32 cycles instead of
@@ -119,7 +136,8 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
 
     const int nkb = (kv_len + 31) / 32;
     constexpr float LOG2E = 1.4426950408889634f;
-    const float sc2 = (QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale) * LOG2E;
+    const float sc1 = QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale;
+    const float sc2 = TOCVP_MHA_EXP2 ? sc1 * LOG2E : sc1;
     // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
     // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
     constexpr int NITM = (32 * F4 + NT - 1) / NT;                  // items per thread (4 waves): DH 64 -> 2, DH 32 -> 1
@@ -198,10 +216,10 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
             }
         }
 
-        // online softmax over keys: in-lane over 16 regs + the other lane half.  Scores are kept in the log2 domain
-        // (scale * log2(e) folded into the one multiplication a score gets anyway), so that an exponential is ONE
-        // v_exp_f32 (the library expf is 13 instructions: 220 of the ~650 vector instructions of a tile); the key mask
-        // is applied in the last tile only and the bias branch is taken once per tile, not once per register.
+        // online softmax over keys: in-lane over 16 regs + the other lane half.  The key mask is applied in the last
+        // tile only and the bias branch is taken once per tile, not once per register (ISA before: 16 exec-mask
+        // branches and 34 compare / select pairs per tile).  TOCVP_MHA_EXP2 (build-time, off): scores in the log2 domain,
+        // one v_exp_f32 per exponential instead of the library expf's 13 instructions -- see mha_exp.
         float bm = NEG_BIG;
         if (p.bias) {
             const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
@@ -209,7 +227,9 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + acc_row(r, h);
-                s[r] = s[r] * sc2 + (key < kv_len ? brow[key] : 0.f) * LOG2E;
+                float sv = s[r] * sc2;
+                if (key < kv_len) sv += brow[key] * (TOCVP_MHA_EXP2 ? LOG2E : 1.f);
+                s[r] = sv;
             }
         } else {
 #pragma unroll
@@ -223,11 +243,11 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
         for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
         const float m_new = fmaxf(m_run, bm);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float alpha = mha_exp(m_run - m_new);
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+            s[r] = mha_exp(s[r] - m_new);
             ps += s[r];
         }
         ps += __shfl_xor(ps, 32, 64);
