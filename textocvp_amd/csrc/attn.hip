@@ -44,10 +44,21 @@ constexpr float NEG_BIG = -1.0e30f;
 #define TOCVP_MHA_EXP2 0
 #endif
 __device__ __forceinline__ float mha_exp(float x) {
+#pragma clang fp contract(off)   // ph must be the ROUNDED product in ph - e, as in the library
 #if TOCVP_MHA_EXP2
     return __builtin_amdgcn_exp2f(x);
 #else
-    return expf(x);
+    // The library's expf for x <= 0 without its two range selects (underflow to 0 below -103.3, overflow above 88.7: four of
+    // its 13 instructions): same operations in the same order, so the same bits -- ph + t = x log2(e) in two floats,
+    // 2^(ph + t - e) by v_exp_f32, scaled by 2^e (v_ldexp_f32 underflows to 0 by itself; masked scores of -1e30 saturate
+    // the integer conversion and come out as 0 too).
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
+    const float ph = x * c;
+    float t = __builtin_fmaf(x, c, -ph);
+    t = __builtin_fmaf(x, cc, t);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + t;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
 #endif
 }
 

@@ -39,6 +39,9 @@ __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
 # is the default: same arithmetic (the producer makes the split the consumer would make), +1.5 % on the step with
 # the decoder overlapped (3694-3704 -> 3754-3759 frames/s, three alternations on one box) and neutral without the
 # overlap (3637-3640 vs 3640-3644): the rollout's GEMMs leave the vector ALUs to the decoder's staging.
+# (end of round 4, with the mid-size chunk GEMM as the consumer: planes for EVERY fitting product -- TOCVP_PRESPLIT=all, the
+# 512-wide output projections included -- 4034 / 4017 vs 4024 / 4036 frames/s at B = 128, 3669 / 3675 vs 3698 / 3698 at 32,
+# 2450 / 2448 vs 2592 / 2571 at 8: "wide" stays)
 _PRESPLIT = os.environ.get("TOCVP_PRESPLIT", "wide")
 # ... and the MLP's hidden activation leaves the up-projection's epilogue as planes for the down-projection (its 2048-deep
 # k-loop then holds no split instructions): another +0.5 % with the decoder overlapped (3799-3807 -> 3819-3827 frames/s,
