@@ -38,8 +38,8 @@ constexpr float NEG_BIG = -1.0e30f;
 // tile) is the default: with -DTOCVP_MHA_EXP2=1 the scores are kept in the log2 domain (scale x log2 e folded into the
 // score's one multiplication) and an exponential is ONE v_exp_f32 -- as accurate against an fp64 softmax (4.4e-7 vs
 // 4.7e-7 at 256 x 8 x 300 x 300 x 64) and 383 vs 447 us, but other last bits: over a four-step rollout one mask pixel
-// whose two largest masks are 2.2e-6 apart in the oracle goes the other way (tests/test_models_gpu.py::
-// test_e2e_against_oracle_fresh_inputs), so it stays a build-time option.
+// whose two largest masks are 2.2e-6 apart in the CPU restatement goes the other way (the fresh-inputs end-to-end test of
+// tests/test_models_gpu.py), so it stays a build-time option.
 #ifndef TOCVP_MHA_EXP2
 #define TOCVP_MHA_EXP2 0
 #endif
