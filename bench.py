@@ -622,6 +622,17 @@ def main():
                                   "avg_launch_ms": round(g_f["total_ms"] / g_f["launches"], 4),
                                   "gflop_per_launch": round(g_f["units"] / g_f["launches"] / 1e9, 2),
                                   "traffic": None, "timed": "extra untimed pass, HIP events per launch"})
+                try:                                   # PMC passes of scripts/mlp_fused_one.py, same row count only
+                    rec = json.load(open(os.path.join(ROOT, "profiles", "mlp_pmc_summary.json")))
+                    if str(rec["rows"]) == name_f[10:].split("x")[0]:
+                        rooflines[-1]["traffic"] = rec["hbm_bytes_per_launch"]
+                        rooflines[-1]["traffic_from"] = (
+                            "profiles/mlp_pmc_summary.json (rocprofv3 PMC on scripts/mlp_fused_one.py, separate FETCH_SIZE / "
+                            "WRITE_SIZE passes, gfx950 x2 fetch correction; bytes from beyond L2 -- the 8 MB of weight planes "
+                            "and the X k-tiles are re-fetched per hidden chunk and mostly served by the Infinity Cache, not "
+                            f"HBM; {rec['ratio']:.1f} x the algorithmic bytes; not this run)")
+                except (OSError, KeyError, ValueError):
+                    pass
             elif g:
                 ns = int(name.split("_")[1][5:])
                 mode, gu = GEMM_UNITS.get(ns, ("split", 3))
