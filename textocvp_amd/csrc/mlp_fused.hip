@@ -61,6 +61,10 @@ struct MlpArgs {
     int n_full, S;
     float* ws_part;                          // [split tile][slice] raw accumulators, REC floats each
     unsigned* ws_ctr;                        // [split tile] arrival counters, zero between launches
+    // zig-zag: odd hidden chunks walk the X k-tiles (and W1's) from the last to the first -- the 32 X images of an XCD (8 MB)
+    // cycle through its 4 MB L2 once per chunk, front to back every time = no hits under LRU; turning round at the end of a
+    // chunk finds the most recent half still there.  Other accumulation order in those chunks: not the default (TOCVP_MLP_ZIGZAG)
+    int zz;
 };
 constexpr int REC = BM * ME;                 // floats per parked accumulator record (256 KB)
 constexpr int WS_CTR_BYTES = 4096;           // 1024 counters
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     // each k-tile's barrier below.  (The hardware still counts these instructions in vmcnt, so the compiler's own counted
     // waits for the weight fragments only ever wait longer than it thinks, never shorter.)
     const unsigned xs_lds = (unsigned)(size_t)xs;                    // LDS byte address of the stage ring
+    auto kphys = [&](int cc, int kt) { return (p.zz && (cc & 1)) ? ME / BK - 1 - kt : kt; };   // physical k-tile of chunk cc
     auto dma_x = [&](unsigned stage_off, int kt, int i0 = 0, int i1 = 8) {
         const unsigned char* base = p.X + (size_t)kt * (BK * 2);     // uniform
         asm volatile("" : "+s"(base));          // an SGPR base per call: nothing per-lane and 64-bit is hoisted out of the loop
@@ -202,7 +207,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
             c = min(c + 1, nchunk - 1);                              // past the end: a harmless re-load, never used
         }
         if (q < 16) {
-            const unsigned char* base = p.W1f + ((size_t)((c * 4 + w) * KS1 + 2 * q) * 2) * 1024;
+            const int qp = 2 * kphys(c, q >> 1) + (q & 1);           // the steps inside a k-tile keep their order
+            const unsigned char* base = p.W1f + ((size_t)((c * 4 + w) * KS1 + 2 * qp) * 2) * 1024;
             asm volatile("" : "+s"(base));
             const gptr g = (gptr)base + lane16;
 #pragma unroll
@@ -322,9 +328,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     // X stage ring (byte offsets): `st_rd` is read by the current k-tile g, `st_nx` holds g + 1, `st_fr` holds g + 2
     // (landed or landing); behind the barrier of k-tile g its stage takes k-tile g + 3
     unsigned st_rd = 0, st_nx = XSTAGE, st_fr = 2 * XSTAGE;
-    dma_x(st_rd, 0);
-    dma_x(st_nx, 1);
-    dma_x(st_fr, 2);
+    dma_x(st_rd, kphys(c_begin, 0));
+    dma_x(st_nx, kphys(c_begin, 1));
+    dma_x(st_fr, kphys(c_begin, 2));
     load_w_half(wr[0], c_begin, 0);
     load_w_half(wr[1], c_begin, 1);
     load_w_half(wr[2], c_begin, 2);
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
             const int q = 2 * kt;
             if (MABL != 2) load_w_half(wr[(q + 3) & 3], c, q + 3);
             // the last DMA instructions of k-tile kt + 2 (begun behind the previous k-tile's barrier, into the stage it read)
-            if (MABL != 1 && DSPLIT < 8 && (kt + 2 < ME / BK || !last)) dma_x(st_fr, (kt + 2) & 7, DSPLIT, 8);
+            if (MABL != 1 && DSPLIT < 8 && (kt + 2 < ME / BK || !last)) dma_x(st_fr, kphys(c + (kt + 2 >= ME / BK), (kt + 2) & 7), DSPLIT, 8);
             read_x(F1, st_rd, 1);
             if (MABL != 4) mfma1(F0, wr[q & 3], 0);
             weave2<12, 8, 4 + (8 - DSPLIT)>();
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
                     for (int i = 0; i < w; ++i) asm volatile("s_nop 15");
             }
             // k-tile kt + 3 (of the next chunk past the end) into the stage this k-tile has just finished reading
-            if (MABL != 1 && (kt + 3 < ME / BK || !last)) dma_x(st_rd, (kt + 3) & 7, 0, DSPLIT);
+            if (MABL != 1 && (kt + 3 < ME / BK || !last)) dma_x(st_rd, kphys(c + (kt + 3 >= ME / BK), (kt + 3) & 7), 0, DSPLIT);
             if (kt + 1 < ME / BK) read_x(F0, st_nx, 0);
             if (MABL != 4) mfma1(F1, wr[(q + 1) & 3], 1);
             if (kt + 1 < ME / BK) weave2<12, 8, DSPLIT>();
@@ -573,6 +579,7 @@ extern "C" int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_fr
         return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
     const int tiles = (M + BM - 1) / BM, cus = mlp_cus(), nchunk = Hd / HC;
+    static const int zz = []() { const char* e = getenv("TOCVP_MLP_ZIGZAG"); return e ? atoi(e) : 0; }();
     int n_full = tiles, S = 1;
     const int left = tiles % cus;
     if (ws && left > 0) {
@@ -587,7 +594,7 @@ extern "C" int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_fr
     MlpArgs p{static_cast<const unsigned char*>(x_planes), static_cast<const unsigned char*>(w1_frag), b1,
               static_cast<const unsigned char*>(w2_frag), b2, R, ldr, Y, ldy, M, Hd, n_full, S,
               ws ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + WS_CTR_BYTES) : nullptr,
-              static_cast<unsigned*>(ws)};
+              static_cast<unsigned*>(ws), zz};
     const dim3 grid((unsigned)(n_full + (tiles - n_full) * S));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (R) hipLaunchKernelGGL(mlp_f16x3_fused_kernel<true>, grid, dim3(256), 0, s, p);
