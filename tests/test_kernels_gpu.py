@@ -932,6 +932,28 @@ def test_mlp_fused_against_the_two_gemms(M, monkeypatch):
     assert int(wk[:1024].view(torch.int32).abs().sum()) == 0
 
 
+def test_mlp_fused_zigzag_order_is_the_same_sum():
+    """
+    TOCVP_MLP_ZIGZAG=1 (opt-in, read once per process: a child process): odd hidden chunks walk the X k-tiles back to front --
+    the same products in another fp32 order.  33000 rows = 256 whole tiles + 2 sliced ones (slices beginning at odd and
+    even chunks): within 2e-5 of the two-GEMM path and as close to float64 as it (scripts/mlp_fused_one.py prints both).
+    """
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOCVP_MLP_ZIGZAG="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "mlp_fused_one.py"), "33000", "2"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"two GEMMs\| ([0-9.e+-]+); max err vs fp64 fused ([0-9.e+-]+) two GEMMs ([0-9.e+-]+)", out.stdout)
+    assert m, out.stdout
+    diff, err, err2 = (float(v) for v in m.groups())
+    print(out.stdout.strip())
+    assert 0.0 < diff < 2e-5 and err < max(2.0 * err2, 1e-5)
+
+
 def test_copy_strided_matches_torch_index_copies():
     """ tocvp_copy4d_f32 behind kernels.copy_strided / contiguous / stack1: the window slices, last-frame slices, stacks and
     the time-major copy of the frames that the hot path used to leave to torch.cat / torch.stack / .contiguous() """
