@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     constexpr int QS = DH + 4;          // padded row stride of Q / K tiles (floats; = 2 fp16 planes + pad)
     constexpr int F4 = DH / 4;          // float4 per row
     constexpr int ND = DH / 32;         // 32-wide blocks of the head dim
-    constexpr int VTB = 144;            // QK16: bytes per row of the transposed V image [dh][32 keys hi | lo | pad]
+    constexpr int VTB = 136;            // QK16: bytes per row of the transposed V image [dh][32 keys hi | lo | pad]: 34 words -- the 32 rows a P V
+                                        // fragment read touches start in 32 different even banks (36 words: 16 banks, two-way conflicts)
     __shared__ __attribute__((aligned(16))) float lds[QB * QS + 32 * QS + (QK16 ? DH * (VTB / 4) : 32 * DH)];
     float* Qs = lds;
     float* Ks = lds + QB * QS;
@@ -152,12 +153,28 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
     // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
     constexpr int NITM = (32 * F4 + NT - 1) / NT;                  // items per thread (4 waves): DH 64 -> 2, DH 32 -> 1
+    // PAIR (dh 64, four waves, split operands): the two items of a thread are keys 2j, 2j + 1 at the SAME head-dim quad, so
+    // that the transposed V image takes whole 4-byte words [key 2j | key 2j + 1] -- 8 ds_write_b32 per thread and tile
+    // instead of 16 ds_write_b16 landing in four banks (PMC before: 61 % of the LDS cycles of this kernel were bank conflicts)
+    constexpr bool PAIR = QK16 && NITM == 2 && 32 * F4 == 2 * NT;
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    auto item = [&](int it, int& r, int& c) {                      // -> false: no such item in this thread
+        if (PAIR) {
+            r = 2 * (t >> 4) + it;
+            c = (t & 15) * 4;
+            return true;
+        }
+        const int i = t + NT * it;
+        r = min(i, 32 * F4 - 1) / F4;
+        c = (min(i, 32 * F4 - 1) % F4) * 4;
+        return i < 32 * F4;
+    };
     f32x4 kreg[NITM], vreg[NITM];
     auto kv_load = [&](int kb) {
 #pragma unroll
         for (int it = 0; it < NITM; ++it) {
-            const int i = min(t + NT * it, 32 * F4 - 1);
-            const int r = i / F4, c = (i % F4) * 4;
+            int r, c;
+            item(it, r, c);                                        // clamped: always a valid address
             const int key = min(kb * 32 + r, p.Tk - 1);
             kreg[it] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk + c);
             vreg[it] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv + c);
@@ -166,11 +183,11 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     kv_load(0);
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();   // previous tile fully consumed (also orders the Q staging)
+        _Float16 vhi[NITM][4], vlo[NITM][4];
 #pragma unroll
         for (int it = 0; it < NITM; ++it) {
-            const int i = t + NT * it;
-            if (i >= 32 * F4) continue;
-            const int r = i / F4, c = (i % F4) * 4;
+            int r, c;
+            if (!item(it, r, c)) continue;
             const bool valid = kb * 32 + r < p.Tk;
             f32x4 kv = kreg[it], vv = vreg[it];
 #pragma unroll
@@ -187,11 +204,23 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
                 for (int u = 0; u < 4; ++u) {
                     const float X = __builtin_amdgcn_fmed3f(vv[u] * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
                     const _Float16 hi = (_Float16)X;
-                    *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + r * 2) = hi;
-                    *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + 64 + r * 2) = (_Float16)(X - (float)hi);
+                    vhi[it][u] = hi;
+                    vlo[it][u] = (_Float16)(X - (float)hi);
+                    if (!PAIR) {
+                        *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + r * 2) = vhi[it][u];
+                        *reinterpret_cast<_Float16*>(vt + (c + u) * VTB + 64 + r * 2) = vlo[it][u];
+                    }
                 }
             } else {
                 *reinterpret_cast<f32x4*>(Vs + r * DH + c) = vv;
+            }
+        }
+        if (PAIR) {
+            unsigned char* vt = reinterpret_cast<unsigned char*>(Vs) + (t & 15) * 4 * VTB + (t >> 4) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                *reinterpret_cast<h16x2*>(vt + u * VTB) = h16x2{vhi[0][u], vhi[NITM - 1][u]};
+                *reinterpret_cast<h16x2*>(vt + u * VTB + 64) = h16x2{vlo[0][u], vlo[NITM - 1][u]};
             }
         }
         kv_load(min(kb + 1, nkb - 1));
