@@ -15,6 +15,8 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
+  # PMC_GROUPS="1 3": only these groups
+  if [ -n "$PMC_GROUPS" ] && ! [[ " $PMC_GROUPS " == *" $i "* ]]; then i=$((i+1)); continue; fi
   d=$out/g$i; mkdir -p $d
   rocprofv3 --pmc $g -d $d --output-format csv -- "$@" > $d/run.log 2>&1 || { echo "group $i failed"; tail -3 $d/run.log; }
   i=$((i+1))
