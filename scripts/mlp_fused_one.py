@@ -4,6 +4,9 @@ difference to the two-GEMM path (0 = bit-identical; TOCVP_MLP_ZIGZAG=1 changes t
 Usage: mlp_fused_one.py [rows] [launches] """
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from textocvp_amd import build as _build
+if os.environ.get("MHA_LIB"):                      # another build of the library (same-box A/B)
+    _build.LIB_PATH = os.path.abspath(os.environ["MHA_LIB"])
 from textocvp_amd import kernels as K
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 76800
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
