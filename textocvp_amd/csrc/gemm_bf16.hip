@@ -319,7 +319,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_bf16_wfrag_kernel(GemmArgs
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
-    const int lr = t / AF4, lc = (t % AF4) * 4;
+    // A staging rows: a ds_write_b64 is serviced in groups of 16 lanes on 32 banks (MI355X_MICROARCH.md, LDS); at BK = 32 a
+    // group holds TWO rows of 8 lanes, and neighbouring rows (36 words apart = 4 mod 32) put 12 of their 16 words on the same
+    // banks (PMC: 33 % of this kernel's LDS cycles were conflicts).  Rows r and r + 4 of an 8-row block are 16 banks apart:
+    // lane pairs (2 m, 2 m + 1) take rows (m, m + 4).  Which thread splits which row changes, nothing else.
+    const int lr0 = t / AF4, lc = (t % AF4) * 4;
+    const int lr = AF4 == 8 ? ((lr0 & ~7) | ((lr0 & 7) >> 1) | ((lr0 & 1) << 2)) : lr0;
     const int KS = p.K / 16;                                // k-steps in total
     const int NBLK = p.N / 32;
 
