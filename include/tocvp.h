@@ -84,7 +84,10 @@ int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsplit, int ns
  * tocvp_split_weights_frag_bf16): B fragments are fetched straight from L2 with coalesced 1 KiB
  * loads and never pass through LDS.  Requires K % 64 == 0 and N % 32 == 0.  With a_split (A given as operand
  * planes (M, planes, K)) one call takes at most 2^32 bytes of planes (32-bit byte offsets; TOCVP_EINVAL beyond: cut
- * the rows). */
+ * the rows).  The SAME limit holds for fp32 A in every split GEMM of this family (tocvp_gemm_bf16split_f32,
+ * tocvp_gemm_bf16wfrag_f32 with a_split == 0, tocvp_gemm_f16wfrag_f32, tocvp_gemm_f16wfrag_ws_f32):
+ * M * lda * 4 < 2^32, TOCVP_EINVAL beyond (rows behind the limit came back wrong, silently, until round 4; the
+ * exact-fp32 tocvp_gemm_f32 has no such limit). */
 int tocvp_split_weights_frag_bf16(const float* w, void* out, int N, int K, int nsplit, void* stream);
 int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wfrag, int nsplit,
                              const float* bias, const float* R, int ldr,

@@ -25,6 +25,7 @@ __all__ = [
     "savi_decomp", "savi_decode", "text_encoder", "adapted_block", "text_ocvp_step", "rollout",
     "forward_eval", "sub", "uncond_step", "encoder_layer_prenorm", "sinusoid_pe",
     "mlp_patch_decoder", "dinosaur_decomp", "t5_encoder", "vit_encoder", "IMAGENET_MEAN",
+    "forward_eval_dinosaur",
 ]
 
 
@@ -304,7 +305,7 @@ def mlp_patch_decoder(sd, slots, img_size, patch_size=14, num_layers_cnn=4):
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # timm.data.IMAGENET_DEFAULT_MEAN = default_cfg["mean"] of the DINOv2 ViTs
 
 
-def vit_encoder(sd, imgs, patch=14, heads=12, eps=1e-6, num_blocks=None):
+def vit_encoder(sd, imgs, patch=14, heads=12, eps=1e-6, num_blocks=None, keep_cls=False):
     """
     imgs (n, 3, H, W) in [0, 1] -> patch features (n, (H/patch)*(W/patch), E).  ``sd``: timm
     VisionTransformer state_dict (keys below ``encoder.vit_backbone.``).
@@ -329,7 +330,7 @@ def vit_encoder(sd, imgs, patch=14, heads=12, eps=1e-6, num_blocks=None):
         y = linear(gelu(linear(y, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
         x = x + (y * p["ls2.gamma"] if "ls2.gamma" in p else y)
         i += 1
-    return x[:, 1:]
+    return x if keep_cls else x[:, 1:]
 
 
 def dinosaur_decomp(sd, feats, noise, iters_first=3, iters=1, trans_heads=4):
@@ -539,11 +540,15 @@ def uncond_step(sd, window, kind, heads=4, buffer_size=10, residual=True):
 
 
 def rollout(sd, slot_history, tokens, lengths, num_context, num_preds, buffer_size=10,
-            teacher_force=False, kind="TextOCVP_CustomTF"):
+            teacher_force=False, kind="TextOCVP_CustomTF", attn_masks=None):
     """ PredictorWrapper.forward, predictor_wrapper.py:50-87 (sd keys start with 'predictor.'). """
     p = sub(sd, "predictor.")
-    text = text_encoder(sub(p, "text_encoder."), tokens, lengths) if kind == "TextOCVP_CustomTF" \
-        else None
+    if kind == "TextOCVP_CustomTF":
+        text = text_encoder(sub(p, "text_encoder."), tokens, lengths)
+    elif kind == "TextOCVP_T5":                                    # predictor_wrapper.py:101-111 (token_dim == 512)
+        text = t5_encoder(sub(p, "text_encoder."), tokens, attn_masks)
+    else:
+        text = None
     window = slot_history[:, :num_context].clone()
     preds = []
     for t in range(num_preds):
@@ -573,3 +578,29 @@ def forward_eval(savi_sd, pred_sd, videos, tokens, lengths, noise, num_context, 
     if return_decode:
         out = out + ({"recons_imgs": imgs, "recons": recons},)
     return out
+
+
+def forward_eval_dinosaur(dino_sd, pred_sd, videos, ids, attn_masks, noise, num_context, num_preds,
+                          buffer_size=10, kind="TextOCVP_T5", lengths=None):
+    """
+    Evaluator.forward_eval (05_evaluate_predictor.py:82-96) on BASELINE configs[3], from PIXELS:
+    ExtendedDINOSAUR.forward_decomp(decode=False) (models/ExtendedDINOSAUR.py:139-208: ViT backbone per frame,
+    linear_feat_proj, slot attention, transition) -> PredictorWrapper(TextOCVP_T5).forward
+    (predictor_wrapper.py:50-87, 101-111) -> ExtendedDINOSAUR.decode (:211-214 -> MLPPatchDecoder,
+    decoders.py:264-365) -> view + clamp.  ``dino_sd`` / ``pred_sd``: reference-layout weight dicts (the
+    backbone under timm's names below 'encoder.vit_backbone.').
+    Returns a dict: encoded_img_feats (B,T,N,768), slot_history (B,T,K,D), pred_slots (B,P,K,D), recons_imgs
+    (B*P,3,S,S) unclamped, pred_imgs (B,P,3,S,S) clamped, recons_feats (B*P,N,F), masks (B*P,K,1,g,g).
+    """
+    B, L, C, H, W = videos.shape
+    T = num_context + num_preds
+    vit = sub(dino_sd, "encoder.vit_backbone.")
+    feats = torch.stack([vit_encoder(vit, videos[:, t]) for t in range(T)], dim=1)
+    hist = dinosaur_decomp(dino_sd, feats, noise)
+    preds = rollout(pred_sd, hist, ids, lengths, num_context, num_preds, buffer_size, kind=kind,
+                    attn_masks=attn_masks)
+    K, D = preds.shape[2:]
+    imgs, recons_feats, masks = mlp_patch_decoder(sub(dino_sd, "decoder."), preds.reshape(B * num_preds, K, D),
+                                                  img_size=H)
+    return {"encoded_img_feats": feats, "slot_history": hist, "pred_slots": preds, "recons_imgs": imgs,
+            "pred_imgs": imgs.view(B, num_preds, C, H, W).clamp(0, 1), "recons_feats": recons_feats, "masks": masks}

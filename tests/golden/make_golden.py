@@ -31,8 +31,90 @@ sys.dont_write_bytecode = True
 from textocvp_amd import synth  # noqa: E402
 
 
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)          # timm.data.constants: default_cfg["mean"] of the DINOv2 ViTs
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+class HFDinov2AsTimm(torch.nn.Module):
+    """
+    transformers.Dinov2Model (an independent third-party implementation of the published DINOv2 ViT) behind the
+    attribute names the reference's ViTEncoder calls on a timm VisionTransformer (timm_encoders.py:59-70: patch_embed,
+    _pos_embed, patch_drop, norm_pre, blocks, default_cfg).  timm itself is absent from the image; with
+    this object the REFERENCE's own wrapper code (std := mean normalisation, class token dropped, final norm skipped)
+    runs here, on HF's arithmetic for the backbone.  HF's ``embeddings`` module does the patch projection, the class
+    token and the position table in one call, so ``patch_embed`` is the identity and ``_pos_embed`` is that module.
+    """
+
+    def __init__(self, img_size=224, patch_size=14, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                 **unused):
+        super().__init__()
+        from transformers import Dinov2Config, Dinov2Model
+        cfg = Dinov2Config(hidden_size=embed_dim, num_hidden_layers=depth, num_attention_heads=num_heads,
+                           mlp_ratio=mlp_ratio, image_size=img_size, patch_size=patch_size, qkv_bias=qkv_bias,
+                           layer_norm_eps=1e-6, hidden_act="gelu", layerscale_value=1e-5,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, drop_path_rate=0.0)
+        cfg._attn_implementation = "eager"
+        self.hf = Dinov2Model(cfg)
+        self.default_cfg = {"mean": IMAGENET_DEFAULT_MEAN, "std": IMAGENET_DEFAULT_STD}
+        self.patch_embed = torch.nn.Identity()
+        self.patch_drop = torch.nn.Identity()
+        self.norm_pre = torch.nn.Identity()
+        self.blocks = torch.nn.Sequential(*self.hf.encoder.layer)
+
+    def _pos_embed(self, x):
+        return self.hf.embeddings(x)
+
+
+def hf_to_timm_key(k):
+    """ transformers.Dinov2Model state_dict name -> (timm VisionTransformer name, row slice index or None) """
+    fixed = {"embeddings.cls_token": "cls_token", "embeddings.position_embeddings": "pos_embed",
+             "embeddings.patch_embeddings.projection.weight": "patch_embed.proj.weight",
+             "embeddings.patch_embeddings.projection.bias": "patch_embed.proj.bias",
+             "layernorm.weight": "norm.weight", "layernorm.bias": "norm.bias"}
+    if k in fixed:
+        return fixed[k], None
+    if not k.startswith("encoder.layer."):
+        return None, None                                   # embeddings.mask_token: pre-training only
+    i, rest = k[len("encoder.layer."):].split(".", 1)
+    for j, name in enumerate(("query", "key", "value")):
+        if rest.startswith(f"attention.attention.{name}."):
+            return f"blocks.{i}.attn.qkv.{rest.rsplit('.', 1)[1]}", j        # fused qkv rows [q | k | v]
+    rest = rest.replace("attention.output.dense.", "attn.proj.")
+    rest = rest.replace("layer_scale1.lambda1", "ls1.gamma").replace("layer_scale2.lambda1", "ls2.gamma")
+    return f"blocks.{i}.{rest}", None
+
+
+@torch.no_grad()
+def fill_hf_dinov2_(hf, prefix, seed=0):
+    """
+    Fill a transformers.Dinov2Model with the synthetic values of the timm-named parameters
+    (``prefix`` + timm name: what synth.fill_module_ gives this repo's ExtendedDINOSAUR / a reference checkpoint layout).
+    Returns the HF -> timm key map that was applied.
+    """
+    applied = {}
+    E = hf.config.hidden_size
+    for k, t in hf.state_dict().items():
+        tk, part = hf_to_timm_key(k)
+        if tk is None:
+            continue
+        shape = tuple(t.shape)
+        if part is not None:
+            shape = (3 * E,) + shape[1:]
+        if tk == "pos_embed":
+            shape = tuple(t.shape)
+        vals = torch.from_numpy(synth._param_values(prefix + tk, shape, seed, "damped"))
+        t.copy_(vals if part is None else vals[part * E:(part + 1) * E])
+        applied[k] = tk if part is None else f"{tk}[{part}E:{part + 1}E]"
+    return applied
+
+
+_REFERENCE = {}
+
+
 def import_reference():
     """ Make `models.*` of the reference importable (stubs for timm / nltk only). """
+    if _REFERENCE:
+        return _REFERENCE["classes"]
     sys.path.insert(0, os.path.join(REF, "src"))
     from transformers import T5EncoderModel  # noqa: F401  (must precede the timm stub)
 
@@ -42,21 +124,29 @@ def import_reference():
         sys.modules[name] = m
         return m
 
-    class _Dummy:  # placeholder for timm's VisionTransformer symbols
+    class _Dummy:  # placeholder for timm symbols nothing here calls
         pass
 
-    _stub("timm")
+    # timm.create_model is what the reference's ViT factories call (timm_encoders.py:215-267); the DINOv2 ones get
+    # the HF model behind timm's attribute names (dinov2 / e2e_c4 fixtures); everything else stays inert
+    def _create_model(name, pretrained=False, **kw):
+        assert "dinov2" in name, name
+        kw.pop("norm_layer", None), kw.pop("num_classes", None)
+        return HFDinov2AsTimm(**kw)
+
+    _stub("timm", create_model=_create_model)
     _stub("timm.models")
     _stub("timm.models.layers", PatchEmbed=_Dummy, trunc_normal_=lambda *a, **k: None)
     _stub("timm.models.resnet", ResNet=_Dummy, Bottleneck=_Dummy, BasicBlock=_Dummy)
-    _stub("timm.models.vision_transformer", VisionTransformer=_Dummy,
+    _stub("timm.models.vision_transformer", VisionTransformer=HFDinov2AsTimm,
           _create_vision_transformer=lambda *a, **k: None)
     _stub("nltk", download=lambda *a, **k: True, word_tokenize=lambda s: s.split())
 
     from models.SAVi import SAVi
     from models.Predictors.text_cond_OCVP import TextOCVP_CustomTF
     from models.Predictors.predictor_wrapper import PredictorWrapper
-    return SAVi, TextOCVP_CustomTF, PredictorWrapper
+    _REFERENCE["classes"] = (SAVi, TextOCVP_CustomTF, PredictorWrapper)
+    return _REFERENCE["classes"]
 
 
 def load_cfg(rel):
@@ -394,9 +484,7 @@ def t5_fixtures(out_dir):
     filled with synthetic weights, which pins the ARITHMETIC of the third-party encoder.
     """
     from transformers import T5Config, T5EncoderModel
-    cfg = T5Config(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8,
-                   relative_attention_num_buckets=32, relative_attention_max_distance=128,
-                   dropout_rate=0.1, layer_norm_epsilon=1e-6, feed_forward_proj="relu")
+    cfg = T5Config(**T5_SMALL)
     m = T5EncoderModel(cfg).eval()
     synth.fill_module_(m, seed=0, prefix="t5.")
     ids = torch.from_numpy(synth._rng("inputs.t5ids", 0).integers(1, 32128, size=(3, 24)))
@@ -412,6 +500,153 @@ def t5_fixtures(out_dir):
     with open(os.path.join(out_dir, "state_dict_manifest_t5.json"), "w") as f:
         json.dump(man, f, indent=0, sort_keys=True)
     print("t5_encoder:", out.shape, float(out.abs().max()))
+
+
+T5_SMALL = dict(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8,
+                relative_attention_num_buckets=32, relative_attention_max_distance=128,
+                dropout_rate=0.1, layer_norm_epsilon=1e-6, feed_forward_proj="relu")      # published t5-small config
+
+VIT_PREFIX = "dino.encoder.vit_backbone."
+
+
+@torch.no_grad()
+def dinov2_fixtures(out_dir):
+    """
+    DINOv2 ViT-B/14 backbone as the reference calls it (timm_encoders.py:59-70, call site ExtendedDINOSAUR.py:187-188):
+    ``(img - mean) / mean`` (std := mean, :54-56) -> patch_embed -> class token + positions -> 12 blocks -> drop the class
+    token, NO final norm.  timm is absent, so the arithmetic of the backbone comes from transformers.Dinov2Model, an
+    independent implementation of the same published model: ``hidden_states[-1][:, 1:]`` of the normalised frames.  The
+    same frames also go through the REFERENCE's ViTEncoder wrapper with that model behind timm's attribute names
+    (HFDinov2AsTimm); both must agree bit for bit.  Weights: the timm-named synthetic values (prefix
+    'dino.encoder.vit_backbone.'), mapped to the HF names by hf_to_timm_key (map stored next to the fixture).
+    Stored: features at 224 (4 frames, every 4th token), the token stream after block 0 (every 16th token), features at
+    the reference's default resolution 336 (1 frame, every 8th token).
+    """
+    import_reference()
+    from models.EncodersDecoders.timm_encoders import ViTEncoder
+    mean = torch.tensor(IMAGENET_DEFAULT_MEAN).view(1, 3, 1, 1)
+    fx, key_map = {}, None
+    for size, frames, step in ((224, synth.synth_videos(2, 2, height=224, width=224, seed=71).flatten(0, 1), 4),
+                               (336, synth.synth_videos(1, 1, height=336, width=336, seed=72).flatten(0, 1), 8)):
+        backbone = HFDinov2AsTimm(img_size=size).eval()
+        key_map = fill_hf_dinov2_(backbone.hf, VIT_PREFIX)
+        out = backbone.hf(pixel_values=(frames - mean) / mean, output_hidden_states=True)
+        feats = out.hidden_states[-1][:, 1:]                              # before the final norm, class token dropped
+        wrapped = ViTEncoder(vit_backbone=backbone).eval()(frames)        # the reference's own forward
+        assert torch.equal(wrapped, feats), float((wrapped - feats).abs().max())
+        fx[f"feats{size}_sub{step}"] = feats[:, ::step].numpy()
+        if size == 224:
+            fx["after_block0_224_sub16"] = out.hidden_states[1][:, ::16].numpy()
+        print(f"dinov2 {size}: feats {tuple(feats.shape)} scale {float(feats.abs().max()):.3g}")
+    np.savez(os.path.join(out_dir, "dinov2_vit.npz"), **fx)
+    with open(os.path.join(out_dir, "dinov2_key_map.json"), "w") as f:
+        json.dump(key_map, f, indent=0, sort_keys=True)
+    print("dinov2_vit:", {k: v.shape for k, v in fx.items()}, "keys mapped", len(key_map))
+
+
+def build_reference_c4(num_slots, num_context, num_preds, img_size=224, buffer_size=10, seed=0, family="undamped"):
+    """
+    The reference's ExtendedDINOSAUR (configs/models/ExtendedDINOSAUR.json at ``img_size``) and
+    PredictorWrapper(TextOCVP_T5) (configs/predictors/TextOCVP_T5.json), constructed the way lib/setup_model.py:21-53,
+    57-132 does, with synthetic weights.  The two third-party encoders the reference downloads are instantiated from
+    their published configs instead: timm's DINOv2 ViT-B/14 as transformers.Dinov2Model behind timm's attribute
+    names (HFDinov2AsTimm), ``T5EncoderModel.from_pretrained("t5-small")`` (text_cond_OCVP.py:148) as
+    ``T5EncoderModel(T5Config(t5-small))``.
+    """
+    import_reference()
+    from transformers import T5Config, T5EncoderModel
+    from models.ExtendedDINOSAUR import ExtendedDINOSAUR
+    from models.Predictors.text_cond_OCVP import TextOCVP_T5
+    from models.Predictors.predictor_wrapper import PredictorWrapper
+    cfg = load_cfg("models/ExtendedDINOSAUR.json")
+    cfg["img_size"], cfg["num_slots"] = img_size, num_slots
+    cfg["decoder"]["decoder_params"]["num_patches"] = (img_size // 14) ** 2
+    model = ExtendedDINOSAUR(**copy.deepcopy(cfg)).eval()
+    synth.fill_module_(model, seed=seed, prefix="dino.", family=family)     # "undamped": sharp alpha masks, RGB bias 0.5
+    fill_hf_dinov2_(model.encoder.vit_backbone.hf, VIT_PREFIX, seed=seed)
+    pred_cfg = load_cfg("predictors/TextOCVP_T5.json")
+    pp = copy.deepcopy(pred_cfg["predictor_params"])
+    pp["predictor_params"]["input_buffer_size"] = buffer_size
+    with mock.patch.object(T5EncoderModel, "from_pretrained",
+                           classmethod(lambda cls, *a, **k: T5EncoderModel(T5Config(**T5_SMALL)))):
+        core = TextOCVP_T5(slot_dim=cfg["slot_dim"], predictor_params=pp["predictor_params"],
+                           fusion_params=pp["fusion_params"], text_encoder_params=pp["text_encoder_params"])
+    exp_params = {
+        "model": {"model_name": "ExtendedDINOSAUR", "model_params": copy.deepcopy(cfg)},
+        "predictor": copy.deepcopy(pred_cfg),
+        "prediction_params": {"num_context": num_context, "num_preds": num_preds,
+                              "teacher_force": False, "input_buffer_size": buffer_size},
+    }
+    wrapper = PredictorWrapper(exp_params=exp_params, predictor=core).eval()
+    synth.fill_module_(wrapper, seed=seed, prefix="pred.")
+    return model, wrapper
+
+
+def c4_inputs(B, L, img_size, seed):
+    """ frames, T5 token ids / attention masks (16 tokens, sample 1 padded from 11) and init noise of the c4 fixtures """
+    videos = synth.synth_videos(B, L, height=img_size, width=img_size, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, 32000, (B, 16), generator=g)
+    mask = torch.ones(B, 16, dtype=torch.int64)
+    if B > 1:
+        mask[1, 11:] = 0
+    return videos, ids * mask, mask
+
+
+@torch.no_grad()
+def e2e_c4_fixtures(out_dir):
+    """
+    BASELINE configs[3] END TO END through the reference's own glue: the three calls of Evaluator.forward_eval
+    (05_evaluate_predictor.py:82-96) on ExtendedDINOSAUR (24 slots, 224 x 224, forward_decomp ExtendedDINOSAUR.py:139-208,
+    decode :211-214 -> MLPPatchDecoder decoders.py:264-365) and PredictorWrapper(TextOCVP_T5), from PIXELS.
+      ``c4``      the workload itself: B = 1, 1 seed + 29 preds;
+      ``c4s``     B = 2, 1 seed + 3 preds, ragged T5 masks (16 / 11 tokens): small enough for the CPU oracle test.
+    Stored per tag: ids, mask, slot_history, pred_slots, the predicted frames (clamped; every 4th pixel at the full
+    workload), the alpha masks (all for c4s; frames 0 / 14 / 28 for c4) and the argmax_K(masks) map of every frame.
+    """
+    fx = {}
+    for tag, B, P, seed in (("c4s", 2, 3, 83), ("c4", 1, 29, 81)):
+        model, wrapper = build_reference_c4(num_slots=24, num_context=1, num_preds=P)
+        videos, ids, mask = c4_inputs(B, 1 + P, 224, seed)
+        noise = synth.synth_noise(B, 24, 128, seed=seed + 1)
+        with FixedNoise(noise):
+            out_model = model(mode="decomp", x=videos, num_imgs=1 + P, decode=False, caption_tokens=ids, attn_masks=mask)
+        hist = out_model["slot_history"]
+        preds = wrapper(hist, caption_tokens=ids, attn_masks=mask)
+        out_dec = model(mode="decode", slots=preds.reshape(B * P, 24, 128))
+        raw = out_dec["recons_imgs"].view(B, P, 3, 224, 224)
+        imgs = raw.clamp(0, 1)
+        masks = out_dec["masks"]                                            # (B * P, 24, 1, 16, 16)
+        fx[f"{tag}_ids"], fx[f"{tag}_mask"] = ids.numpy(), mask.numpy()
+        fx[f"{tag}_slot_history"], fx[f"{tag}_pred_slots"] = hist.numpy(), preds.numpy()
+        fx[f"{tag}_feats_f0_sub8"] = out_model["encoded_img_feats"][:, 0, ::8].numpy()
+        if tag == "c4s":
+            fx[f"{tag}_pred_imgs_sub2"] = imgs[..., ::2, ::2].numpy()
+            fx[f"{tag}_masks"] = masks.numpy()
+            fx[f"{tag}_recons_feats_sub8"] = out_dec["recons_feats"][:, ::8, ::8].numpy()
+        else:
+            fx[f"{tag}_pred_imgs_sub4"] = imgs[..., ::4, ::4].numpy()
+            fx[f"{tag}_masks_f0_14_28"] = masks[[0, 14, 28]].numpy()
+        fx[f"{tag}_masks_argmax"] = masks.argmax(dim=1).to(torch.uint8).numpy()
+        top2 = masks.topk(2, dim=1).values
+        print(f"e2e_{tag}: hist {tuple(hist.shape)} preds {tuple(preds.shape)} imgs [{float(raw.min()):.3f}, "
+              f"{float(raw.max()):.3f}] clamped share {float(((raw < 0) | (raw > 1)).float().mean()):.3f} masks max {float(masks.max()):.3f} slots |max| {float(preds.abs().max()):.3g} "
+              f"min top-2 mask margin {float((top2[:, 0] - top2[:, 1]).min()):.3g}", flush=True)
+    np.savez(os.path.join(out_dir, "e2e_c4.npz"), **fx)
+    # checkpoint-layout contract of the configs[3] pair: the reference modules' own state_dict names and shapes; the
+    # backbone's entries are listed under timm's names (what a reference checkpoint holds), derived from the HF
+    # model through hf_to_timm_key
+    dsd, E = model.state_dict(), model.encoder.vit_backbone.hf.config.hidden_size
+    man_d = {k: list(v.shape) for k, v in dsd.items() if not k.startswith("encoder.vit_backbone.")}
+    for k, v in model.encoder.vit_backbone.hf.state_dict().items():
+        tk, part = hf_to_timm_key(k)
+        if tk is not None:
+            man_d["encoder.vit_backbone." + tk] = ([3 * E] if part is not None else [v.shape[0]]) + list(v.shape[1:])
+    man = {"ExtendedDINOSAUR": man_d, "PredictorWrapper_T5": {k: list(v.shape) for k, v in wrapper.state_dict().items()}}
+    with open(os.path.join(out_dir, "state_dict_manifest_c4.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("manifest c4:", len(man["ExtendedDINOSAUR"]), len(man["PredictorWrapper_T5"]))
+    print("e2e_c4:", {k: v.shape for k, v in fx.items()})
 
 
 def train_fixtures(out_dir):
@@ -473,7 +708,7 @@ def manifest(out_dir):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     what = sys.argv[1:] or ["manifest", "units", "e2e", "parity", "longcap", "decomp", "uncond", "dinosaur", "t5",
-                            "train"]
+                            "train", "dinov2", "e2e_c4"]
     if "manifest" in what:
         manifest(HERE)
     if "units" in what:
@@ -494,3 +729,7 @@ if __name__ == "__main__":
         t5_fixtures(HERE)
     if "train" in what:
         train_fixtures(HERE)
+    if "dinov2" in what:
+        dinov2_fixtures(HERE)
+    if "e2e_c4" in what:
+        e2e_c4_fixtures(HERE)

@@ -159,6 +159,21 @@ def test_dinosaur_layout_and_vit_backbone_keys():
         model.encoder(torch.zeros(1, 3, 64, 64))                                # timm: input size must match
 
 
+def test_config4_pair_layout_matches_the_reference_modules():
+    """ configs[3]: the WHOLE state_dict of ExtendedDINOSAUR (24 slots, 224 px) and of PredictorWrapper(TextOCVP_T5)
+    equals, name by name and shape by shape, the manifest captured from the reference's own modules
+    (state_dict_manifest_c4.json, make_golden.py::e2e_c4_fixtures; the backbone's entries under timm's names,
+    mapped from transformers.Dinov2Model through dinov2_key_map.json) """
+    import json
+    from textocvp_amd.setup_model import default_dinosaur_params
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest_c4.json")))
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == man["ExtendedDINOSAUR"]
+    pred = setup_predictor(default_exp_params(num_slots=24, num_preds=29, predictor_name="TextOCVP_T5"))
+    assert {k: list(v.shape) for k, v in pred.state_dict().items()} == man["PredictorWrapper_T5"]
+    assert len(man["ExtendedDINOSAUR"]) == 255 and len(man["PredictorWrapper_T5"]) == 273
+
+
 def test_t5_predictor_layout():
     """ TextOCVP_T5: text_encoder.* keys are those of transformers.T5EncoderModel (t5-small) """
     import json

@@ -740,6 +740,81 @@ def test_vit_backbone_and_decomp_from_pixels_against_oracle():
 
 
 @torch.no_grad()
+def test_vit_backbone_against_dinov2_golden():
+    """
+    Row a11, the backbone, PINNED (round 5): the DINOv2 ViT-B/14 forward of timm_encoders.py:59-70 on the kernels
+    against transformers.Dinov2Model run through the reference's ViTEncoder wrapper (dinov2_vit.npz,
+    make_golden.py::dinov2_fixtures; the oracle holds the same vectors to 6.5e-7 relative,
+    test_oracle_golden.py::test_vit_oracle_vs_dinov2).  224 x 224 and the reference's default 336 x 336 (577 tokens).
+    Bar: 2e-5 of the feature scale (~40: LayerScale gains are O(1) in the synthetic weights, 1e-5 in a checkpoint).
+    """
+    from textocvp_amd.setup_model import default_dinosaur_params
+    g = load_golden("dinov2_vit.npz")
+    for size, frames, step in ((224, synth.synth_videos(2, 2, height=224, width=224, seed=71), 4),
+                               (336, synth.synth_videos(1, 1, height=336, width=336, seed=72), 8)):
+        model = setup_model(default_dinosaur_params(num_slots=24, img_size=size)).eval()
+        synth.fill_module_(model, prefix="dino.")
+        enc = model.encoder.to(DEV)
+        ref = torch.from_numpy(g[f"feats{size}_sub{step}"])
+        scale = float(ref.abs().max())
+        feats = enc(gpu(frames)).flatten(0, 1)
+        err = max_abs(feats[:, ::step].cpu(), ref)
+        print(f"ViT-B/14 {size}: kernels vs transformers.Dinov2Model {err:.2e} at scale {scale:.3g}")
+        assert feats.shape == (frames.shape[0] * frames.shape[1], (size // 14) ** 2, 768) and err < 2e-5 * scale
+        del model, enc
+
+
+def _config4_pair(P):
+    from textocvp_amd.setup_model import default_dinosaur_params
+    model = setup_model(default_dinosaur_params(num_slots=24, img_size=224)).eval()
+    exp = default_exp_params(num_slots=24, num_context=1, num_preds=P, predictor_name="TextOCVP_T5")
+    pred = setup_predictor(exp).eval()
+    synth.fill_module_(model, prefix="dino.", family="undamped")         # sharp alpha masks (synth.py)
+    synth.fill_module_(pred, prefix="pred.")
+    return model, pred
+
+
+@pytest.mark.parametrize("tag,B,P,seed,sub", [("c4s", 2, 3, 83, 2), ("c4", 1, 29, 81, 4)])
+@torch.no_grad()
+def test_e2e_config4_against_reference_golden(tag, B, P, seed, sub):
+    """
+    BASELINE configs[3] END TO END FROM PIXELS against the reference's own glue (e2e_c4.npz: ExtendedDINOSAUR.forward_decomp
+    models/ExtendedDINOSAUR.py:139-208 -> PredictorWrapper(TextOCVP_T5) predictor_wrapper.py:50-87 -> decode :211-214 ->
+    clamp, the three calls of 05_evaluate_predictor.py:82-96; transformers' Dinov2Model / T5EncoderModel as the two
+    third-party encoders):  "c4" = the workload itself, B = 1, 24 slots, 224 x 224, 1 seed + 29 preds;  "c4s" = B = 2,
+    1 + 3, ragged T5 masks.  Bar: 1e-4 on slots, predicted frames and alpha masks, IDENTICAL argmax_K(masks) maps.
+    The same inputs through the CPU oracle (O.forward_eval_dinosaur) hold the golden to 1.3e-5
+    (test_oracle_golden.py::test_e2e_c4_*); at "c4s" this test runs the oracle as well (every pixel, recons_feats).
+    """
+    g = load_golden("e2e_c4.npz")
+    model, pred = _config4_pair(P)
+    dsd = {k: v.clone() for k, v in model.state_dict().items()}
+    psd = {k: v.clone() for k, v in pred.state_dict().items()}
+    model, pred = model.to(DEV), pred.to(DEV)
+    videos = synth.synth_videos(B, 1 + P, height=224, width=224, seed=seed)
+    noise = synth.synth_noise(B, 24, 128, seed=seed + 1)
+    ids, mask = torch.from_numpy(g[f"{tag}_ids"]), torch.from_numpy(g[f"{tag}_mask"])
+    out = forward_eval(model, pred, gpu(videos), 1, P, caption_tokens=gpu(ids), attn_masks=gpu(mask), init_noise=noise)
+    fs = float(np.abs(g[f"{tag}_feats_f0_sub8"]).max())
+    errs = {"slot_history": max_abs(out["slot_history"].cpu(), g[f"{tag}_slot_history"]),
+            "pred_slots": max_abs(out["pred_slots"].cpu(), g[f"{tag}_pred_slots"]),
+            "pred_imgs": max_abs(out["pred_imgs"][..., ::sub, ::sub].cpu(), g[f"{tag}_pred_imgs_sub{sub}"])}
+    if tag == "c4s":
+        errs["masks"] = max_abs(out["masks"].cpu(), g["c4s_masks"])
+    else:
+        errs["masks"] = max_abs(out["masks"][[0, 14, 28]].cpu(), g["c4_masks_f0_14_28"])
+    print(f"e2e_{tag} vs reference golden:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert out["pred_imgs"].shape == (B, P, 3, 224, 224) and out["masks"].shape == (B * P, 24, 1, 16, 16)
+    assert max(errs.values()) < 1e-4, errs
+    assert_same_slot_assignment(out["masks"], g[f"{tag}_masks_argmax"], f"e2e_{tag} (reference golden)")
+    if tag == "c4s":
+        ref = O.forward_eval_dinosaur(dsd, psd, videos, ids, mask, noise, 1, P)
+        assert max_abs(out["pred_imgs"].cpu(), ref["pred_imgs"]) < 1e-4          # every pixel
+        assert max_abs(out["pred_slots"].cpu(), ref["pred_slots"]) < 1e-4
+        assert_same_slot_assignment(out["masks"], ref["masks"].argmax(dim=1), f"e2e_{tag} (oracle)")
+
+
+@torch.no_grad()
 def test_e2e_config4_dinosaur_from_pixels_properties():
     """
     BASELINE configs[3] at its workload: ExtendedDINOSAUR (ViT-B/14 backbone) 24 slots, 224x224, 1 seed + 29

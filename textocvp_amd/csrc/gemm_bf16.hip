@@ -974,6 +974,8 @@ extern "C" int tocvp_gemm_bf16split_f32(const float* A, int lda, const void* Wsp
     TOCVP_CHECK_ARG(nsplit == 2 || nsplit == 3);
     TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 32) == 0);
     TOCVP_CHECK_ARG(lda >= K && ldc >= N);
+    // A is addressed with 32-bit byte offsets: at most 2^32 bytes of activations per call (the caller cuts rows)
+    TOCVP_CHECK_ARG((size_t)M * (size_t)lda * sizeof(float) < 0x100000000ull);
     TOCVP_CHECK_ARG(R == nullptr || ldr >= N);
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
     TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
@@ -1006,6 +1008,7 @@ extern "C" int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, con
     TOCVP_CHECK_ARG(a_split || lda >= K);
     // operand planes are addressed with 32-bit byte offsets: at most 2^32 bytes of planes per call (the caller cuts rows)
     TOCVP_CHECK_ARG(!a_split || (size_t)M * (nsplit == 22 ? 2 : nsplit) * K * 2 < 0x100000000ull);
+    TOCVP_CHECK_ARG(a_split || (size_t)M * (size_t)lda * sizeof(float) < 0x100000000ull);     // the same for fp32 rows
     TOCVP_CHECK_ARG(c_split || ldc >= N);
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));
@@ -1040,6 +1043,7 @@ extern "C" int tocvp_gemm_f16wfrag_ws_f32(const void* A, int lda, const void* Wf
                                           int K, int act, void* ws, size_t ws_bytes, void* stream) {
     TOCVP_CHECK_ARG(A && Wfrag && C);
     TOCVP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 64) == 0 && (N % 32) == 0 && lda >= K);
+    TOCVP_CHECK_ARG((size_t)M * (size_t)lda * sizeof(float) < 0x100000000ull);               // 32-bit byte offsets into A
     TOCVP_CHECK_ARG(c_split || ldc >= N);
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0 && tocvp_aligned16(R)));
     TOCVP_CHECK_ARG(rowvec == nullptr || (rv_div > 0 && rv_mod > 0));

@@ -86,6 +86,7 @@ def _param_values(name, shape, seed, family="damped"):
       "damped"    the round-1 weights: RGB rows of the decoder head scaled by 0.05 (pixels inside (0, 1));
       "undamped"  the same weights with an O(1) RGB head (plain He-uniform rows, alpha row x2): pixel
                   errors of the decoder arithmetic are NOT attenuated, rendered values leave [0, 1];
+                  ExtendedDINOSAUR: alpha row of the MLPPatchDecoder head x12 (sharp masks), RGB bias 0.5;
       "xavier"    the distribution of the reference's own init (see _xavier_values).
     """
     if family not in FAMILIES:
@@ -109,6 +110,20 @@ def _param_values(name, shape, seed, family="damped"):
             w[:-1] *= 0.05
         w[-1:] *= 2.0
         return w
+    if family == "undamped" and ".decoder.mlp." in name and len(shape) == 2 and shape[0] % 2 == 1:
+        # MLPPatchDecoder head (features + 1 alpha logit, decoders.py:264-283): a x12 alpha row gives sharp,
+        # informative masks (with plain He rows the alpha-softmax over 24 slots stays within 1.5x of uniform and the
+        # argmax_K(masks) map hangs on 1e-6 margins); the default family keeps the round-1 values
+        w = synth_array(name, shape, "uniform", scale=math.sqrt(6.0 / shape[1]), seed=seed)
+        w[-1:] *= 12.0
+        return w
+    if family == "undamped" and name.endswith("decoder.pos_embed"):
+        # learned patch positions of the MLPPatchDecoder at the scale of the slots, so that WHICH slot wins a patch
+        # depends on the patch (with +-0.2 positions against +-10 slots one slot takes every patch of a frame)
+        return synth_array(name, shape, "normal", scale=2.0, seed=seed)
+    if family == "undamped" and "conv_patch_decoder" in name and last == "bias" and tuple(shape) == (3,):
+        # RGB bias of the CNN image head: rendered pixels around 0.5 so that the evaluator's clamp rarely saturates
+        return 0.5 + synth_array(name, shape, "uniform", scale=0.2, seed=seed)
     if name.endswith("mlp_out.weight"):
         # residual predictor: keep the per-step slot update small so a 19-step rollout stays O(1)
         return synth_array(name, shape, "uniform", scale=0.02 * math.sqrt(6.0 / shape[1]),
