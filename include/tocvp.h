@@ -240,6 +240,20 @@ int tocvp_mha_qk16_rows_split_f16(const float* Q, int ldq, const float* K, int l
 int tocvp_mha_one_query_split_f16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Osplit,
                                   int B, int H, int Tq_total, int q_row, int Tk, int dh, float scale, const int32_t* key_len,
                                   void* stream);
+/* Round 5 -- the same attention with q / k / v given as fp16 OPERAND PLANES, as the epilogue of the projection GEMM writes
+ * them (tocvp_gemm_* with c_split: rows [hi of all columns | lo of all columns] of 2^8 x): MultiHeadSelfAttention.forward
+ * (attention.py:245-265) in the predictor blocks, the ViT blocks of timm_encoders.py:59-70.  dh = 64 only.
+ *   Q / K / V: f16 pointers ALREADY offset to the first column of the q / k / v block; ldq / ldk / ldv = plane stride in
+ *   elements (= the projection's output width; a token row is 2 ld* elements; multiples of 8); samples are Tq_total (Q, O) and
+ *   Tk (K, V) rows apart.  Exactly one of O (fp32 rows, stride ldo) and Osplit (fp16 planes (B * Tq_total, 2, H * 64)) is given.
+ *   The launch covers the first q_rows query rows of every sample.  (Sequence lengths of 128 n + 1 simply take a third,
+ *   nearly empty query block here: its keys / values are L2 hits and the kernel no longer splits or transposes them, 346 us
+ *   at 256 x 12 x 257 against 516 us with a one-row vector-ALU kernel beside it.)
+ * The kernel only copies the planes into LDS (no split, no transpose: V fragments by ds_read_b64_tr_b16) and is otherwise
+ * the arithmetic of tocvp_mha_qk16_f32 expression for expression: BIT-IDENTICAL to it on the values the planes encode. */
+int tocvp_mha_planes_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, float* O, int ldo,
+                         void* Osplit, int B, int H, int Tq_total, int q_rows, int Tk, int dh, float scale,
+                         const int32_t* key_len, void* stream);
 /* same, O written as operand planes: (B*Tq, nsplit, H*dh) bf16 (nsplit 2 or 3) or, nsplit 22,
  * (B*Tq, 2, H*dh) fp16 planes of 2^8 O */
 int tocvp_mha_split_bf16(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

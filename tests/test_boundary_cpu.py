@@ -284,3 +284,56 @@ def test_dropin_alias_package_resolves_the_reference_imports():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), root]))
     res = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "alias ok" in res.stdout, res.stderr[-2000:]
+
+
+def test_cached_module_parameters_follow_every_way_of_replacing_them():
+    """
+    ``model_utils.cached_params`` (the per-module parameter tuples of the host-bound small-batch path) must never hand
+    out a REPLACED parameter: attribute assignment, sub-module swap, ``load_state_dict(assign=True)``, parametrizations
+    and ``.to()`` under ``set_overwrite_module_params_on_conversion`` each give a fresh tuple; plain ``load_state_dict`` /
+    in-place updates keep the objects (their data changes in place, which the derived-weight caches follow).
+    """
+    import torch.nn as nn
+    import torch.nn.utils.parametrize as parametrize
+    from textocvp_amd.models.Blocks.attention import TransformerBlock
+    from textocvp_amd.models.Blocks.model_utils import cached_params
+
+    def get_ln(m):
+        return cached_params(m.layernorm_query, lambda ln: (ln.weight, ln.bias, ln.eps))
+
+    def get_mlp(m):
+        return cached_params(m.mlp, lambda s: (s[0].weight, s[0].bias, s[2].weight, s[2].bias))
+
+    blk = TransformerBlock(embed_dim=128, num_heads=4, mlp_size=256, pre_norm=False)
+    w0 = get_ln(blk)[0]
+    assert get_ln(blk)[0] is w0 is blk.layernorm_query.weight
+    blk.load_state_dict({k: v + 1 for k, v in blk.state_dict().items()})             # in place: same objects
+    assert get_ln(blk)[0] is w0
+    blk.layernorm_query.weight = nn.Parameter(torch.full((128,), 3.0))              # attribute assignment
+    assert get_ln(blk)[0] is blk.layernorm_query.weight and float(get_ln(blk)[0][0]) == 3.0
+    old = get_mlp(blk)[0]
+    blk.mlp[0] = nn.Linear(128, 256)                                                 # sub-module swap
+    assert get_mlp(blk)[0] is blk.mlp[0].weight and get_mlp(blk)[0] is not old
+    old = get_mlp(blk)[2]
+    blk.load_state_dict({k: v.clone() for k, v in blk.state_dict().items()}, assign=True)
+    assert get_mlp(blk)[2] is blk.mlp[2].weight and get_mlp(blk)[2] is not old
+
+    class Double(nn.Module):
+        def forward(self, w):
+            return 2.0 * w
+    parametrize.register_parametrization(blk.mlp[2], "weight", Double())            # recomputed per access: never cached
+    with torch.no_grad():
+        a = get_mlp(blk)[2]
+        blk.mlp[2].parametrizations.weight.original.add_(1.0)
+        b = get_mlp(blk)[2]
+    assert torch.equal(b, a + 2.0)
+
+    blk2 = TransformerBlock(embed_dim=128, num_heads=4, mlp_size=256, pre_norm=False)
+    w0 = get_ln(blk2)[0]
+    prev = torch.__future__.get_overwrite_module_params_on_conversion()
+    torch.__future__.set_overwrite_module_params_on_conversion(True)
+    try:
+        blk2.double()
+    finally:
+        torch.__future__.set_overwrite_module_params_on_conversion(prev)
+    assert blk2.layernorm_query.weight is not w0 and get_ln(blk2)[0] is blk2.layernorm_query.weight

@@ -971,8 +971,15 @@ def test_copy_strided_matches_torch_index_copies():
     assert torch.equal(k.contiguous(toks.reshape(4, 10, 30, 512)[:, -1]), toks.reshape(4, 10, 30, 512)[:, -1].contiguous())
     parts = [torch.randn(6, 7, 128, generator=g).to(DEV) for _ in range(4)]
     assert torch.equal(k.stack1(parts), torch.stack(parts, dim=1))
-    with pytest.raises(k.TocvpError):
-        k.copy_strided(hist[..., :6], torch.empty(5, 20, 30, 6, device=DEV))        # runs of 6 floats: not 16-byte pieces
+    # layouts the kernel does not take fall through to torch's device copy instead of failing (round 5): runs of 6 floats,
+    # a base pointer that is not 16-byte aligned (an odd image width), four strided dimensions
+    odd = k.copy_strided(hist[..., :6], torch.empty(5, 20, 30, 6, device=DEV))
+    assert torch.equal(odd, hist[..., :6])
+    flat = torch.randn(4 * 33 * 33 + 1, generator=g).to(DEV)
+    assert torch.equal(k.contiguous(flat[1:].reshape(4, 33, 33).transpose(1, 2)), flat[1:].reshape(4, 33, 33).transpose(1, 2).contiguous())
+    assert torch.equal(k.contiguous(hist[::2, ::3, ::5, ::4]), hist[::2, ::3, ::5, ::4].contiguous())
+    misaligned = flat[1:1 + 4 * 32 * 8].reshape(4, 32, 8)
+    assert misaligned.data_ptr() % 16 != 0 and torch.equal(k.contiguous(misaligned.transpose(0, 1)), misaligned.transpose(0, 1).contiguous())
 
 
 @pytest.mark.parametrize("M,N,Kd", [(4096, 1024, 1024), (1157, 1536, 512), (1000, 512, 128), (77, 1024, 3072),
@@ -1225,3 +1232,50 @@ def test_fp32_input_split_gemms_beyond_four_gigabytes_of_activations(prec):
     for rows in (slice(0, 256), slice(1048576 - 128, 1048576 + 128), slice(M - 256, M)):
         ref = torch.relu(x[rows].double() @ w.double().t() + b.double())
         assert (y[rows].double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), rows
+
+
+def _planes_of(x2):
+    """ fp16 operand planes (rows, 2, D) of 2^8 x, the split of tocvp_store_planes4 (common.h) spelled in torch """
+    X = torch.clamp(x2 * 256.0, -65504.0, 65504.0)
+    hi = X.to(torch.float16)
+    return torch.stack([hi, (X - hi.float()).to(torch.float16)], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,lens", [(5, 8, 300, 300, False), (3, 8, 30, 300, False), (2, 8, 77, 77, True),
+                                            (24, 12, 257, 257, True), (1, 8, 30, 30, False), (9, 6, 257, 257, False)])
+def test_mha_planes_equals_the_fp32_input_kernel(B, H, Tq, Tk, lens, monkeypatch):
+    """
+    csrc/attn_planes.hip (round 5): self-attention of the predictor / ViT blocks (reference attention.py:183-215, 245-265;
+    timm_encoders.py:59-70) with q / k / v handed over as the fp16 operand planes a projection epilogue writes.  The kernel
+    copies planes where tocvp_mha_qk16_f32 splits and transposes fp32 rows, and keeps its arithmetic instruction for
+    instruction: the fp32 output and the plane output must equal the fp32-input kernel's BIT FOR BIT on the same values --
+    whole sequences, the last-frame queries of the final predictor layer (30 query rows against 300 keys, q from its own
+    projection), ragged key lengths, the ViT's 128 n + 1 rows, fused-projection column offsets; and fp32-class against the
+    float64 attention of the oracle.
+    """
+    k = _k()
+    dh, E = 64, H * 64
+    monkeypatch.setattr(k, "_MHA_TAIL_ROW", False)               # reference: the tile kernel on every row (no one-row kernel)
+    kv = rnd("pkv", (B, Tk, 3 * E)).to(DEV)                       # fused projection: columns [q | k | v]
+    qsep = rnd("pq", (B, Tq, E)).to(DEV) if Tq != Tk else None     # a separate query projection (forward_last)
+    kl = None
+    if lens:
+        lengths = torch.full((B,), Tk, dtype=torch.int64)
+        lengths[0], lengths[B - 1] = max(1, Tk - 7), max(1, Tk // 2 + 3)
+        kl = lengths.to(torch.int32).to(DEV)
+    q32 = qsep if qsep is not None else kv[..., :E]
+    ref = k.mha(q32, kv[..., E:2 * E], kv[..., 2 * E:], H, dh ** -0.5, key_len=kl)
+    ref_pl = k.mha(q32, kv[..., E:2 * E], kv[..., 2 * E:], H, dh ** -0.5, key_len=kl, out_split=22)
+    kvp = k.SplitAct(_planes_of(kv.reshape(B * Tk, 3 * E)), (B, Tk, 3 * E))
+    qp, qcol = (kvp, 0) if qsep is None else (k.SplitAct(_planes_of(qsep.reshape(B * Tq, E)), (B, Tq, E)), 0)
+    with k.gemm_precision("f16x3"):
+        assert k.mha_planes_ok(H, E)
+        got = k.mha_planes(qp, qcol, kvp, E, kvp, 2 * E, B, Tq, Tk, H, dh ** -0.5, key_len=kl)
+        got_pl = k.mha_planes(qp, qcol, kvp, E, kvp, 2 * E, B, Tq, Tk, H, dh ** -0.5, key_len=kl, out_split=22)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert torch.equal(got_pl.planes, ref_pl.planes)
+    pad = None if kl is None else (torch.arange(1, Tk + 1)[None, :] > kl.cpu().long()[:, None])
+    o64 = O.attention(q32.cpu().double(), kv[..., E:2 * E].cpu().double(), kv[..., 2 * E:].cpu().double(), H, dh ** -0.5, key_mask=pad)
+    assert (got.cpu().double() - o64).abs().max().item() < 2e-6
+    again = k.mha_planes(qp, qcol, kvp, E, kvp, 2 * E, B, Tq, Tk, H, dh ** -0.5, key_len=kl)
+    assert torch.equal(again, got)

@@ -24,6 +24,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def extra_flags(src):
+    """ per-file compiler flags: a source may carry ``// TOCVP_HIPCC_FLAGS: <flags>`` lines in its first 40 lines
+    (e.g. ``-mllvm -amdgpu-mfma-vgpr-form`` for a kernel whose accumulators are rescaled by vector instructions) """
+    flags = []
+    with open(src) as f:
+        for _, line in zip(range(40), f):
+            if line.startswith("// TOCVP_HIPCC_FLAGS:"):
+                flags += line.split(":", 1)[1].split()
+    return flags
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -49,7 +60,7 @@ def build(force=False, verbose=False):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_m):
             continue
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-comment",
-               f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
+               f"-I{INCLUDE}", f"-I{CSRC}"] + extra_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

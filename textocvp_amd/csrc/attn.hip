@@ -34,34 +34,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// Exponential of the online softmax.  The library expf (13 instructions: 220 of the ~650 vector instructions of a 32-key
-// tile) is the default: with -DTOCVP_MHA_EXP2=1 the scores are kept in the log2 domain (scale x log2 e folded into the
-// score's one multiplication) and an exponential is ONE v_exp_f32 -- as accurate against an fp64 softmax (4.4e-7 vs
-// 4.7e-7 at 256 x 8 x 300 x 300 x 64) and 383 vs 447 us, but other last bits: over a four-step rollout one mask pixel
-// whose two largest masks are 2.2e-6 apart in the CPU restatement goes the other way (the fresh-inputs end-to-end test of
-// tests/test_models_gpu.py), so it stays a build-time option.
-#ifndef TOCVP_MHA_EXP2
-#define TOCVP_MHA_EXP2 0
-#endif
-__device__ __forceinline__ float mha_exp(float x) {
-#pragma clang fp contract(off)   // ph must be the ROUNDED product in ph - e, as in the library
-#if TOCVP_MHA_EXP2
-    return __builtin_amdgcn_exp2f(x);
-#else
-    // The library's expf for x <= 0 without its two range selects (underflow to 0 below -103.3, overflow above 88.7: four of
-    // its 13 instructions): same operations in the same order, so the same bits -- ph + t = x log2(e) in two floats,
-    // 2^(ph + t - e) by v_exp_f32, scaled by 2^e (v_ldexp_f32 underflows to 0 by itself; masked scores of -1e30 saturate
-    // the integer conversion and come out as 0 too).
-    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
-    const float ph = x * c;
-    float t = __builtin_fmaf(x, c, -ph);
-    t = __builtin_fmaf(x, cc, t);
-    const float e = __builtin_rintf(ph);
-    const float a = (ph - e) + t;
-    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
-#endif
-}
-
+// Exponentials of the online softmax (round 5): ONE v_exp_f32 each, in the log2 domain -- p = 2^(fma(score, k2, -max k2))
+// with k2 = scale log2(e) on the raw accumulator scores (no per-score multiplication; the argument carries the one rounding
+// of the fma).  Rounds 3-4 used the library expf's operations (13, then 9 instructions per exponential: 40 % of the vector
+// instructions of a kernel bound by their issue, profiles/r04_mha.md, r05_mha.md); against a float64 softmax the two forms
+// are equally accurate (tests/test_kernels_gpu.py::test_mha*).  The plane-input kernel (attn_planes.hip) uses the same
+// expressions: the two kernels agree bit for bit.
 // QK16: BOTH products run on the f16 matrix cores with split operands (hi + lo fp16 planes of 2^8 x, three
 // v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of gemm_bf16.hip Elem<true>, |q|, |k|,
 // |v| < 255): per 32-key tile and 32 queries at dh = 64, 12 + 12 matrix instructions of 32 cycles instead of
@@ -149,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
     const int nkb = (kv_len + 31) / 32;
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc1 = QK16 ? p.scale * (1.f / (TOCVP_F16X3_ACT_SCALE * TOCVP_F16X3_ACT_SCALE)) : p.scale;
-    const float sc2 = TOCVP_MHA_EXP2 ? sc1 * LOG2E : sc1;
+    const float k2 = sc1 * LOG2E;                                  // log2-domain scale of the raw scores
     // K / V tiles are prefetched one tile ahead in registers (clamped, always-valid addresses; rows past Tk
     // are zeroed when stored): the global-memory latency of tile kb+1 runs under the products of tile kb.
     constexpr int NITM = (32 * F4 + NT - 1) / NT;                  // items per thread (4 waves): DH 64 -> 2, DH 32 -> 1
@@ -257,42 +235,55 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
         }
 
         // online softmax over keys: in-lane over 16 regs + the other lane half.  The key mask is applied in the last
-        // tile only and the bias branch is taken once per tile, not once per register (ISA before: 16 exec-mask
-        // branches and 34 compare / select pairs per tile).  TOCVP_MHA_EXP2 (build-time, off): scores in the log2 domain,
-        // one v_exp_f32 per exponential instead of the library expf's 13 instructions -- see mha_exp.
-        float bm = NEG_BIG;
+        // tile only and the bias branch is taken once per tile, not once per register.  Without a bias the scores stay RAW
+        // (maximum, fma(score, k2, -max k2), v_exp_f32); with one (T5's relative positions) they move to the log2 domain first.
+        float bm = NEG_BIG, alpha, ps = 0.f;
+        const bool mask_tile = kb * 32 + 32 > kv_len;   // wave-uniform: only the last tile holds keys past the end
         if (p.bias) {
             const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
             const float* brow = p.bias + ((size_t)head * p.Tq + q) * p.Tk;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + acc_row(r, h);
-                float sv = s[r] * sc2;
-                if (key < kv_len) sv += brow[key] * (TOCVP_MHA_EXP2 ? LOG2E : 1.f);
+                float sv = s[r] * k2;
+                if (key < kv_len) sv += brow[key] * LOG2E;
                 s[r] = sv;
             }
+            if (mask_tile) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kb * 32 + acc_row(r, h) < kv_len) ? s[r] : NEG_BIG;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float m_new = fmaxf(m_run, bm);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                ps += s[r];
+            }
+            m_run = m_new;
         } else {
+            if (mask_tile) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= sc2;
-        }
-        if (kb * 32 + 32 > kv_len) {   // wave-uniform: only the last tile holds keys past the end
+                for (int r = 0; r < 16; ++r) s[r] = (kb * 32 + acc_row(r, h) < kv_len) ? s[r] : NEG_BIG;
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = (kb * 32 + acc_row(r, h) < kv_len) ? s[r] : NEG_BIG;
-        }
+            for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float m_new = fmaxf(m_run, bm);
+            const float mk = m_new * k2;
+            alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, k2, -mk));   // first tile / masked scores: 2^(-1e25) = 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-        const float m_new = fmaxf(m_run, bm);
-        const float alpha = mha_exp(m_run - m_new);
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = mha_exp(s[r] - m_new);
-            ps += s[r];
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], k2, -mk));
+                ps += s[r];
+            }
+            m_run = m_new;
         }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
-        m_run = m_new;
         // the running maximum settles after the first tiles: the accumulators (AGPRs: read, multiply, write back = 83
         // instructions) are rescaled only when some query of the wave saw a new maximum (alpha = 1 exactly otherwise)
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {

@@ -105,6 +105,10 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
         ctypes.c_void_p, ctypes.c_void_p]),
+    "tocvp_mha_planes_f16": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+        ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_copy4d_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_void_p,
                                         ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -545,7 +549,8 @@ _COPY_PLANS = {}
 
 def copy_strided(src, dst):
     """ dst[...] = src[...] (same shape, fp32, same device) through tocvp_copy4d_f32; returns dst.  Views whose layout the
-    kernel does not take (more than three strided dimensions, runs that are not multiples of 4 floats) raise. """
+    kernel does not take (more than three strided dimensions, runs that are not multiples of 4 floats, bases that are not
+    16-byte aligned) are copied by torch (index copies are data movement, not arithmetic). """
     if not _LIB_COPIES:
         dst.copy_(src)
         return dst
@@ -555,12 +560,18 @@ def copy_strided(src, dst):
         _dev_f32(src, "copy source"), _dev_f32(dst, "copy destination")
         assert src.shape == dst.shape, (src.shape, dst.shape)
         plan = _copy_plan(src, dst) if src.numel() else ([(0, 0, 0)] * 3, 0)
-        if plan is None:
-            raise TocvpError(f"copy_strided: unsupported views {tuple(src.shape)} {src.stride()} -> {dst.stride()}")
+        if plan is None or plan[1] >= 2 ** 31 or any(n >= 2 ** 31 for n, _, _ in plan[0]):
+            # a layout the kernel does not take (more than three strided dimensions, runs or strides that are not
+            # multiples of 4 floats -- odd image sizes, permuted dataloader layouts -- or extents beyond 32 bits):
+            # pure data movement, left to torch's own device copy
+            plan = "torch"
         if len(_COPY_PLANS) < 4096:
             _COPY_PLANS[key] = plan
     if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_cuda or not dst.is_cuda:
         raise TocvpError("copy_strided: fp32 tensors on the GPU only")
+    if plan == "torch" or (src.data_ptr() | dst.data_ptr()) & 15:       # 16-byte loads / stores need aligned bases
+        dst.copy_(src)
+        return dst
     (n0, a0, b0), (n1, a1, b1), (n2, a2, b2) = plan[0]
     if n0 * n1 * n2 == 0:
         return dst
@@ -1061,6 +1072,48 @@ def mha(q, k, v, heads, scale, key_len=None, out_split=0, bias=None):
         fn(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(o), E, B, heads, Tq, Tk,
            dh, float(scale), _ptr(key_len), _stream()), "tocvp_mha_f32"))
     return o
+
+
+# self-attention on q / k / v operand planes written by the projection's epilogue (csrc/attn_planes.hip, round 5): the kernel
+# copies the planes instead of splitting / transposing fp32 rows per query block.  TOCVP_MHA_PLANES=0: fp32 hand-over
+_MHA_PLANES = os.environ.get("TOCVP_MHA_PLANES", "1") != "0"
+
+
+def mha_planes_ok(heads, E):
+    """ the plane-input attention serves head dim 64 under the default f16x3 arithmetic, outside the range-checked pass
+    (a plane-producing epilogue saturates without a check of its own: the checked pass keeps fp32 hand-overs) """
+    return (_MHA_PLANES and _ATTN_QK16 and not _CHECK_RANGE and active_nsplit() == 22 and E == heads * 64 and E % 64 == 0)
+
+
+def mha_planes(q, q_col, k, k_col, v, v_col, B, Tq, Tk, heads, scale, key_len=None, out_split=0):
+    """
+    q: SplitAct whose planes (B * Tq, 2, ldq) hold the query projection in columns q_col .. q_col + E; k, v likewise with
+    (B * Tk, 2, ld) planes (the three may share one fused projection).  Returns (B, Tq, E) fp32, or a SplitAct (fp16 planes)
+    if out_split == 22.  Bit-identical to ``mha`` on the fp32 values the planes encode.
+    """
+    dh = 64
+    E = heads * dh
+    for name, t, rows in (("q", q, B * Tq), ("k", k, B * Tk), ("v", v, B * Tk)):
+        pl = t.planes
+        assert pl.dtype == torch.float16 and pl.is_cuda and pl.is_contiguous() and pl.shape[0] == rows and pl.shape[1] == 2, \
+            (name, pl.dtype, tuple(pl.shape), rows)
+    if key_len is not None:
+        assert key_len.dtype == torch.int32 and key_len.is_cuda and key_len.numel() == B
+    dev = q.planes.device
+    o = osp = None
+    if out_split:
+        assert out_split == 22
+        osp = _alloc_planes(B * Tq, 22, E, dev)
+    else:
+        o = torch.empty((B, Tq, E), device=dev, dtype=torch.float32)
+    qp, kp, vp = q.planes.data_ptr() + 2 * q_col, k.planes.data_ptr() + 2 * k_col, v.planes.data_ptr() + 2 * v_col
+    ldq, ldk, ldv = q.planes.shape[2], k.planes.shape[2], v.planes.shape[2]
+
+    def run():
+        _check(lib().tocvp_mha_planes_f16(qp, ldq, kp, ldk, vp, ldv, _ptr(o), E, _ptr(osp), B, heads, Tq, Tq, Tk, dh, float(scale),
+                                          _ptr(key_len), _stream()), "tocvp_mha_planes_f16")
+    _timed(lambda: f"mha_{B}x{heads}x{Tq}x{Tk}x{dh}", 4.0 * B * heads * Tq * Tk * dh, run)
+    return SplitAct(osp, (B, Tq, E)) if out_split else o
 
 
 def slot_attn_workspace(B, N, device):

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import kernels as K
-from .model_utils import Derived, init_xavier_, require_inference
+from .model_utils import Derived, cached_params, init_xavier_, require_inference, tracks_structure
 
 __all__ = ["SlotAttention", "MultiHeadSelfAttention", "MultiHeadCrossAttention",
            "TransformerBlock", "TransformerDecoderBlock", "AdaptedEncoderBlock"]
@@ -78,16 +78,7 @@ class TextKV:
         self.kv, self.collapsed = kv, collapsed
 
 
-def _params(mod, build):
-    """ tuple of a module's parameters / constants for the hot path, cached in the module's __dict__: on a host-bound step
-    (8 sequences: 2400 launches from Python) nn.Module.__getattr__ and nn.Sequential.__getitem__ are a measurable share of
-    the time per launch (scripts/host_profile.py).  Parameter OBJECTS survive load_state_dict / .to() (their data is
-    replaced in place), so the tuple stays valid. """
-    p = mod.__dict__.get("_tocvp_params")
-    if p is None:
-        p = build(mod)
-        mod.__dict__["_tocvp_params"] = p
-    return p
+_params = cached_params          # model_utils: per-module tuples, dropped when a parameter object is replaced
 
 
 def _ln(x, ln, add=None, split=0):
@@ -133,6 +124,7 @@ def _mlp(x, seq, residual):
 SD_PLANES = 128          # slot dim of the plane-input slot-attention kernel
 
 
+@tracks_structure
 class SlotAttention(nn.Module):
     """
     Iterative slot attention (reference attention.py:12-128; algorithm :86-110).
@@ -246,6 +238,7 @@ class SlotAttention(nn.Module):
         return m if shape is None else m.reshape(m.shape[0], m.shape[1], *shape)
 
 
+@tracks_structure
 class MetaAttention(nn.Module):
     """ q/k/v/out parameter holder shared by self- and cross-attention (reference :136-215). """
 
@@ -288,6 +281,14 @@ class MultiHeadSelfAttention(MetaAttention):
         wq, wk, wv, wo, heads = _params(self, lambda m: (m.q.weight, m.k.weight, m.v.weight, m.out_projection[0].weight,
                                                           m.num_heads))
         w = self._derived.get("w_qkv", [wq, wk, wv], lambda: torch.cat([wq, wk, wv], 0).contiguous())
+        if K.mha_planes_ok(heads, E):
+            # head dim 64 (the predictor blocks): the projection's epilogue writes q / k / v as fp16 operand planes and the
+            # attention kernel copies them (csrc/attn_planes.hip) instead of splitting / transposing fp32 rows per query block
+            B, T = x.shape[0], x.shape[1]
+            qkv = K.linear(x, w, chunk_ok=_CHUNK_GEMM, out_split=22)      # planes (B T, 2, 3E)
+            o = K.mha_planes(qkv, 0, qkv, E, qkv, 2 * E, B, T, T, heads, (E // heads) ** -0.5,
+                             out_split=_ns(E, n_out=wo.shape[0]))
+            return K.linear(o, wo, residual=residual)
         qkv = K.linear(x, w, chunk_ok=_CHUNK_GEMM)                        # (B, T, 3E)
         o = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, (E // heads) ** -0.5,
                   out_split=_ns(E, n_out=wo.shape[0]))
@@ -304,6 +305,11 @@ class MultiHeadSelfAttention(MetaAttention):
         B, T, E = x.shape
         w_kv = self._derived.get("w_kv", [self.k.weight, self.v.weight],
                                  lambda: torch.cat([self.k.weight, self.v.weight], 0).contiguous())
+        if K.mha_planes_ok(self.num_heads, E):
+            kv = K.linear(x, w_kv, chunk_ok=_CHUNK_GEMM, out_split=22)    # planes (B T, 2, 2E)
+            q = K.linear(K.contiguous(x[:, T - n_last:]), self.q.weight, out_split=22)
+            o = K.mha_planes(q, 0, kv, 0, kv, E, B, n_last, T, self.num_heads, (E // self.num_heads) ** -0.5)
+            return K.linear(o, self.out_projection[0].weight, residual=residual_last)
         kv = K.linear(x, w_kv, chunk_ok=_CHUNK_GEMM)                      # (B, T, 2E)
         q = K.linear(K.contiguous(x[:, T - n_last:]), self.q.weight)      # (B, n_last, E)
         o = K.mha(q, kv[..., :E], kv[..., E:], self.num_heads, (E // self.num_heads) ** -0.5)
@@ -377,6 +383,7 @@ class MultiHeadCrossAttention(MetaAttention):
         return K.linear(o, self.out_projection.weight, self.out_projection.bias, residual=residual)
 
 
+@tracks_structure
 class TransformerBlock(nn.Module):
     """
     Transformer encoder block (reference :323-396): pre-norm by default, POST-norm when used as the
@@ -408,6 +415,7 @@ class TransformerBlock(nn.Module):
         return _ln(_mlp(y, self.mlp, residual=y), self.layernorm_mlp)
 
 
+@tracks_structure
 class TransformerDecoderBlock(nn.Module):
     """ Cross-attention + MLP, both pre-norm with residuals (reference :400-467). """
 

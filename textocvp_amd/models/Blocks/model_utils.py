@@ -7,7 +7,70 @@ import torch
 import torch.nn as nn
 
 __all__ = ["init_xavier_", "Derived", "require_inference", "RangeGuard", "refuse_replication", "freeze_params",
-           "unfreeze_params", "count_model_params"]
+           "unfreeze_params", "count_model_params", "structure_epoch", "tracks_structure", "cached_params"]
+
+
+# ------------------------------------------------------------------------------------------------
+# Structure epoch: a process-wide counter that moves whenever ANY nn.Module gets a parameter, buffer or
+# sub-module (re)registered -- ``mod.weight = nn.Parameter(...)``, ``block.mlp = ...``, ``load_state_dict(assign=True)``
+# (it goes through ``setattr``), ``parametrize.register_parametrization``, pruning / weight_norm (they register
+# ``*_orig`` / ``*_g`` parameters) -- or one of this package's modules goes through ``_apply`` (``.to()`` / ``.float()``
+# with ``torch.__future__.set_overwrite_module_params_on_conversion(True)`` puts NEW Parameter objects into
+# ``_parameters`` without registering them).  ``cached_params`` keeps per-module tuples of Parameter objects for the
+# host-bound small-batch path and drops them when the epoch moved: a replaced parameter can never be computed with.
+# ------------------------------------------------------------------------------------------------
+
+_EPOCH = [0]
+
+
+def _bump(*args, **kwargs):
+    _EPOCH[0] += 1
+    return None                                   # registration hooks: None keeps the registered object
+
+
+nn.modules.module.register_module_parameter_registration_hook(_bump)
+nn.modules.module.register_module_module_registration_hook(_bump)
+nn.modules.module.register_module_buffer_registration_hook(_bump)
+
+
+def structure_epoch():
+    return _EPOCH[0]
+
+
+def tracks_structure(cls):
+    """ class decorator: ``_apply`` (``.to`` / ``.cuda`` / ``.float`` ...) moves the structure epoch """
+    orig = cls._apply
+
+    def _apply(self, fn, *args, **kwargs):
+        _bump()
+        return orig(self, fn, *args, **kwargs)
+    cls._apply = _apply
+    return cls
+
+
+def _volatile(mod):
+    """ modules whose ``weight`` is recomputed per access or per forward (parametrizations; weight_norm / pruning set it
+    from a forward pre-hook): their attributes are never cached """
+    for m in mod.modules():
+        if "parametrizations" in m._modules or m._forward_pre_hooks:
+            return True
+    return False
+
+
+def cached_params(mod, build):
+    """
+    ``build(mod)`` -> tuple of the module's parameters / constants for the hot path, cached in the module's __dict__:
+    on a host-bound step (8 sequences: 2400 launches from Python) nn.Module.__getattr__ and nn.Sequential.__getitem__
+    are a measurable share of the time per launch (scripts/host_profile.py).  ``load_state_dict`` / ``.to()`` replace the
+    parameters' DATA in place (the derived-weight caches follow data_ptr / _version); every way of replacing the
+    OBJECTS moves the structure epoch (above), which invalidates the tuple here.
+    """
+    hit = mod.__dict__.get("_tocvp_params")
+    if hit is not None and hit[0] == _EPOCH[0]:
+        return hit[1]
+    vals = build(mod)
+    mod.__dict__["_tocvp_params"] = (-1 if _volatile(mod) else _EPOCH[0], vals)
+    return vals
 
 
 @torch.no_grad()

@@ -196,9 +196,15 @@ class ViTEncoder(nn.Module):
                         n * (N + 1) >= _VIT_PLANES_MIN_ROWS) else 0
             for i, blk in enumerate(vb.blocks):
                 y = K.layer_norm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, split=ns)
-                qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
-                a = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], blk.attn.num_heads,
-                          (E // blk.attn.num_heads) ** -0.5, out_split=ns if K._ATTN_QK16 else 0)
+                if K.mha_planes_ok(blk.attn.num_heads, E):
+                    # q / k / v leave the projection's epilogue as fp16 operand planes; the attention kernel copies them
+                    qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias, out_split=22)
+                    a = K.mha_planes(qkv, 0, qkv, E, qkv, 2 * E, n, N + 1, N + 1, blk.attn.num_heads,
+                                     (E // blk.attn.num_heads) ** -0.5, out_split=ns)
+                else:
+                    qkv = K.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
+                    a = K.mha(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], blk.attn.num_heads,
+                              (E // blk.attn.num_heads) ** -0.5, out_split=ns if K._ATTN_QK16 else 0)
                 w, b = self._scaled(("proj", i), blk.attn.proj, blk.ls1)
                 x = K.linear(a, w, b, residual=x)
                 y = K.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, split=ns)

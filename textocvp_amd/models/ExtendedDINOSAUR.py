@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import kernels as K
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
-from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference, tracks_structure
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 from .EncodersDecoders.encoders import get_encoder
@@ -26,6 +26,7 @@ from .EncodersDecoders.encoders import get_encoder
 __all__ = ["ExtendedDINOSAUR"]
 
 
+@tracks_structure
 class ExtendedDINOSAUR(nn.Module, RangeGuard):
     _replicate_for_data_parallel = refuse_replication      # one process per GPU, never DataParallel replicas
 

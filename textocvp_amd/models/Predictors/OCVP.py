@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from ... import kernels as K
-from ..Blocks.model_utils import require_inference
+from ..Blocks.model_utils import require_inference, tracks_structure
 
 __all__ = ["VanillaTransformerPredictor", "OCVPSeq", "OCVPSeqLayer"]
 
@@ -48,6 +48,7 @@ def _make_layer(token_dim, n_heads, hidden_dim):
                                       norm_first=True, dim_feedforward=hidden_dim)
 
 
+@tracks_structure
 class _SlotPredictorBase(nn.Module):
     def __init__(self, num_slots, slot_dim, token_dim, hidden_dim, num_layers, n_heads, residual,
                  input_buffer_size):
@@ -95,6 +96,7 @@ class VanillaTransformerPredictor(_SlotPredictorBase):
         return self._head(x.reshape(B, w, Ks, self.token_dim)[:, -1], slots)
 
 
+@tracks_structure
 class OCVPSeqLayer(nn.Module):
     """ object attention within a frame, then time attention per slot (OCVP.py:267-320) """
 

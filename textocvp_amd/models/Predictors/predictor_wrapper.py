@@ -6,11 +6,12 @@ import torch
 import torch.nn as nn
 
 from ... import kernels as K
-from ..Blocks.model_utils import RangeGuard, refuse_replication
+from ..Blocks.model_utils import RangeGuard, refuse_replication, tracks_structure
 
 __all__ = ["PredictorWrapper"]
 
 
+@tracks_structure
 class PredictorWrapper(nn.Module, RangeGuard):
 
     """

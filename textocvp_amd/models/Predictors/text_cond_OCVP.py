@@ -13,12 +13,13 @@ from ... import kernels as K
 from ...precision import knob
 from ..Blocks.attention import AdaptedEncoderBlock
 from ..Blocks.model_blocks import TemporalPositionalEncoding
-from ..Blocks.model_utils import require_inference
+from ..Blocks.model_utils import require_inference, tracks_structure
 from ..EncodersDecoders.text_encoders import TransformerTextEncoder
 
 __all__ = ["TextOCVP_CustomTF", "TextOCVP_T5", "T5TextEncoder"]
 
 
+@tracks_structure
 class BaseTextOCVP(nn.Module):
     """
     slots of the input window -> ``mlp_in`` (+ flipped learned temporal PE fused in the GEMM

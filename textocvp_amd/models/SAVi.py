@@ -15,7 +15,7 @@ from ..precision import knob
 from .Blocks.attention import SlotAttention
 from .Blocks.initializers import get_initializer
 from .Blocks.model_blocks import SoftPositionEmbed
-from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference
+from .Blocks.model_utils import RangeGuard, init_xavier_, refuse_replication, require_inference, tracks_structure
 from .Blocks.transition_models import get_transition_module
 from .EncodersDecoders.decoders import get_decoder
 from .EncodersDecoders.encoders import get_encoder
@@ -23,6 +23,7 @@ from .EncodersDecoders.encoders import get_encoder
 __all__ = ["SAVi"]
 
 
+@tracks_structure
 class SAVi(nn.Module, RangeGuard):
     """
     Same constructor kwargs (= keys of configs/models/SAVi.json), ``forward(mode=...)`` contract,
