@@ -119,14 +119,24 @@ __global__ __launch_bounds__(64 * NW) void mha_planes_kernel(MhaPArgs p) {
     const unsigned char* Vb = reinterpret_cast<const unsigned char*>(p.V + (size_t)b * p.Tk * 2 * p.ldv + head * DH);
     const int pr = t >> 4, pcp = t & 15;
     u32x4 kreg[2], vreg[2];
+    // byte offsets inside this sample's planes stay below 2^32 (Tk x 4 ld bytes) and the factors below 2^24: one
+    // v_mad_u32_u24 per piece on top of the lane-constant chunk offsets (64-bit address arithmetic per piece cost a dozen
+    // quarter-rate integer multiplies per tile)
+    const unsigned rowb_k = 4u * (unsigned)p.ldk, rowb_v = 4u * (unsigned)p.ldv;       // a key row = 2 planes of 2-byte elements
+    unsigned ck_off[2], cv_off[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = pr + 16 * it;
+        const int ck = pcp ^ (r & 15), cv = pcp ^ ((r & 3) << 2);              // logical chunks of this physical chunk
+        ck_off[it] = (unsigned)((ck >> 3) * p.ldk + (ck & 7) * 8) * 2u;
+        cv_off[it] = (unsigned)((cv >> 3) * p.ldv + (cv & 7) * 8) * 2u;
+    }
     auto kv_load = [&](int kb) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int r = pr + 16 * it;
-            const int key = min(kb * 32 + r, p.Tk - 1);       // rows past the end repeat the last key (masked / weight 0)
-            const int ck = pcp ^ (r & 15), cv = pcp ^ ((r & 3) << 2);          // logical chunks of this physical chunk
-            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (((size_t)key * 2 + (ck >> 3)) * p.ldk + (ck & 7) * 8) * 2);
-            vreg[it] = *reinterpret_cast<const u32x4*>(Vb + (((size_t)key * 2 + (cv >> 3)) * p.ldv + (cv & 7) * 8) * 2);
+            const unsigned key = (unsigned)min(kb * 32 + pr + 16 * it, p.Tk - 1);   // rows past the end repeat the last key
+            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (size_t)(__umul24(key, rowb_k) + ck_off[it]));
+            vreg[it] = *reinterpret_cast<const u32x4*>(Vb + (size_t)(__umul24(key, rowb_v) + cv_off[it]));
         }
     };
     auto kv_write = [&](int stage) {
@@ -314,6 +324,8 @@ static int planes_args_ok(const void* Q, int ldq, const void* K, int ldk, const 
     TOCVP_CHECK_ARG(B >= 0 && H > 0 && Tq_total > 0 && Tk > 0 && dh == 64);
     TOCVP_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && (Osplit || ldo >= H * dh));
     TOCVP_CHECK_ARG((long)B * H <= 0x7fffff);
+    // 24-bit factors / 32-bit byte offsets inside one sample's planes (attn_planes.hip::kv_load)
+    TOCVP_CHECK_ARG(Tk < (1 << 24) && ldk < (1 << 22) && ldv < (1 << 22) && (size_t)Tk * 4 * (ldk > ldv ? ldk : ldv) < 0xffff0000ull);
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (O && (ldo & 3)) || !tocvp_aligned16(Q) || !tocvp_aligned16(K) ||
         !tocvp_aligned16(V) || (O && !tocvp_aligned16(O)) || (Osplit && !tocvp_aligned16(Osplit)))
         return TOCVP_EALIGN;
