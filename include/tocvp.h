@@ -94,29 +94,6 @@ int tocvp_gemm_bf16wfrag_f32(const void* A, int a_split, int lda, const void* Wf
                              const float* rowvec, int rv_div, int rv_mod, int rv_flip,
                              void* C, int c_split, int ldc, int M, int N, int K, int act,
                              void* stream);
-/* ---------------------------------------------------------------------------------------------
- * f16x3 GEMM on fp16 operand planes of BOTH operands (gemm_f16p.hip): C = act(A W^T + bias) + R.
- *   A_planes: (M, 2, K) fp16 planes of 2^8 x, as the split epilogues / tocvp_layernorm_split_bf16 write them;
- *   W_planes: (N, 2, K) fp16 planes of 2^10 w from tocvp_split_weights_planes_f16 (once per weight version);
- *   C: fp32 (M, N) with row stride ldc, or (c_split) fp16 planes (M, 2, N) for a following planes GEMM.
- * N % 256 == 0, K % 32 == 0.  Both operands reach LDS by DMA (no conversion, no staging registers),
- * 256 x 256 or 128 x 256 tiles, 8 waves.  Replaces nn.Linear at Blocks/attention.py:167-175, 355-359.
- * ------------------------------------------------------------------------------------------- */
-int tocvp_split_weights_planes_f16(const float* w, void* out, int N, int K, void* stream);
-int tocvp_gemm_f16planes_f32(const void* A_planes, const void* W_planes, const float* bias, const float* R,
-                             int ldr, void* C, int c_split, int ldc, int M, int N, int K, int act,
-                             void* stream);
-/* Same product with a workspace (tocvp_gemm_f16planes_ws_bytes() bytes, 16-byte aligned, ZEROED ONCE when it is
- * allocated; the kernel leaves its flag words zero again).  With it the persistent kernel may cut the k-tiles of the
- * whole product into equal contiguous ranges, one per CU ("stream-K"): products whose tile count does not fill the
- * last round of CUs (300 tiles of 38400 x 512 on 256 CUs) run ~1.6x faster.  A tile cut between two workgroups is
- * summed in k order by the holder of its first range (deterministic: same result on every run for a given shape).
- * One workspace serves any number of launches that are ordered on ONE stream; concurrent streams need one each. */
-size_t tocvp_gemm_f16planes_ws_bytes(void);
-int tocvp_gemm_f16planes_ws_f32(const void* A_planes, const void* W_planes, const float* bias, const float* R,
-                                int ldr, void* C, int c_split, int ldc, int M, int N, int K, int act, void* ws,
-                                size_t ws_bytes, void* stream);
-
 /* "f16x3": the same kernel with fp16 planes (x = hi + lo in fp16, 22 significant bits, products
  * hh + hl + lh): fp32-class accuracy at HALF the MFMA count of bf16x6, valid while |x| < 65504. */
 int tocvp_split_weights_frag_f16(const float* w, void* out, int N, int K, void* stream);
@@ -155,14 +132,11 @@ int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag, const floa
                             void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream);
 /* The same structure for mid-size row counts (600 .. 10 000 rows: the predictor's products at small evaluation batches,
  * models/Blocks/attention.py:167-175, 355-359, 428-432): 64 rows x 256 outputs per workgroup, two workgroups per CU, A in
- * 128-deep chunks by LDS-DMA, weights from L2 in fragment order; N % 256 == 0, K % 128 == 0.  With a workspace
- * (tocvp_gemm_f16mid_ws_bytes() bytes, 16-byte aligned, ZERO before its first use, one per stream that may run
- * concurrently) K is split over idle CUs: every slice parks its raw accumulators, the last arriver of a tile adds the
- * slices in slice order (deterministic; the arrival counters re-arm themselves) and runs the epilogue.  ws == NULL: never
- * split, and then bit-identical to tocvp_gemm_bf16wfrag_f32 on the same operands.  Arguments as tocvp_gemm_f16chunk_f32. */
-size_t tocvp_gemm_f16mid_ws_bytes(void);
+ * 128-deep chunks by LDS-DMA, weights from L2 in fragment order; N % 256 == 0, K % 128 == 0.  Bit-identical to
+ * tocvp_gemm_bf16wfrag_f32 on the same operands.  Arguments as tocvp_gemm_f16chunk_f32.  (A split-K form through a
+ * workspace existed in round 4, measured slower than the unsplit launch and was retired.) */
 int tocvp_gemm_f16mid_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr, void* C,
-                          int c_split, int ldc, int M, int N, int K, int act, void* ws, size_t ws_bytes, void* stream);
+                          int c_split, int ldc, int M, int N, int K, int act, void* stream);
 int tocvp_gemm_f16wfrag_f32(const void* A, int lda, const void* Wfrag, const float* bias,
                             const float* R, int ldr, const float* rowvec, int rv_div, int rv_mod,
                             int rv_flip, void* C, int ldc, int M, int N, int K, int act, void* stream);
@@ -378,9 +352,8 @@ int tocvp_conv5x5_f16f8_f32(const float* x, const float* aux, int in_mode, const
  * matrix cores (three v_mfma_f32_32x32x16_f16 into one fp32 accumulator): ~2^-21 per product, i.e.
  * fp32-class.  Replaces nn.Conv2d(64,64,5,padding=2)+ReLU of ConvDecoder (decoders.py:96-110).
  * Valid for |x| < 255 and |w| < 63 (operands saturate beyond).  in_mode / aux as tocvp_conv5x5_f32,
- * layout bits 0 / 1 as tocvp_conv5x5_f16f8_f32; bit 2 selects the persistent form of the kernel (one workgroup
- * per CU walks its tiles with the next halo staged behind the MFMAs of the current one; same results);
- * bit 3 (with bit 0 and / or 1, not with bit 2): the pass-major buffers hold fp16 OPERAND PLANES -- per pixel and
+ * layout bits 0 / 1 as tocvp_conv5x5_f16f8_f32; bit 2 is refused (TOCVP_EINVAL: the persistent form of rounds 2-4 is retired);
+ * bit 3 (with bit 0 and / or 1): the pass-major buffers hold fp16 OPERAND PLANES -- per pixel and
  * 16-channel pass the 64 bytes [16 f16 Xh | 16 f16 Xl] of 2^8 x instead of 16 floats.  A layer called with bits 1 + 3
  * writes them from its epilogue (the split the next layer's staging would make of the same values), a layer called
  * with bits 0 + 3 stages them into LDS by DMA without converting: the chain gives bit-identical results to the fp32

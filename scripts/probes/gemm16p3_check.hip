@@ -2,7 +2,7 @@
 // (same products, same k order), timings, and the in-kernel stamps of planes3.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itextocvp_amd/csrc -DTOCVP_P3_STAMP \
 //         -o scripts/probes/gemm16p3_check scripts/probes/gemm16p3_check.hip ;  ./gemm16p3_check [M N K [MI [skew [grid]]]]
-#include "../../textocvp_amd/csrc/gemm_f16p.hip"
+#include "gemm_f16p.hip"
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>

@@ -1,7 +1,7 @@
 // Timing ablations of the all-DMA planes GEMM (results are NOT correct for ABLATE != 0).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itextocvp_amd/csrc -DTOCVP_GEMM_P2_ABLATE=n \
 //         -o scripts/probes/gemm16p_ablate_n scripts/probes/gemm16p_ablate.hip ;  ./gemm16p_ablate_n [M N K]
-#include "../../textocvp_amd/csrc/gemm_f16p.hip"
+#include "gemm_f16p.hip"
 #include <stdio.h>
 #include <vector>
 

@@ -1,7 +1,7 @@
 // Where a workgroup of the all-DMA planes GEMM spends its cycles: s_memtime stamps at the phase boundaries.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itextocvp_amd/csrc -DTOCVP_P2_STAMP \
 //         -o scripts/probes/gemm16p_stamp scripts/probes/gemm16p_stamp.hip ;  ./gemm16p_stamp [M N K]
-#include "../../textocvp_amd/csrc/gemm_f16p.hip"
+#include "gemm_f16p.hip"
 #include <stdio.h>
 #include <algorithm>
 #include <vector>

@@ -1,3 +1,5 @@
+// RETIRED FROM THE LIBRARY (round 5): the all-DMA planes GEMMs (planes2, persistent planes3, stream-K) lost their A/B in the
+// rollout (profiles/r03_gemm_planes3.md) and were opt-in only; kept here for the probes that include this file.
 // f16x3 GEMM on fp16 OPERAND PLANES of both operands:  C = act(A W^T + bias) + R
 //
 // Replaces nn.Linear of the predictor blocks (reference models/Blocks/attention.py:167-175, 355-359,

@@ -586,17 +586,6 @@ def test_conv5x5_dec_f16x3_is_fp32_class(n):
     assert err[1].max().item() < 3e-6                    # relative accuracy at the small image's own scale
     got_lin = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=False)
     assert (got_lin.cpu().double() - lin).abs().max().item() < max(2.5 * err32, 2e-6 * lin.abs().max().item())
-    # the persistent form of the kernel (off by default) runs the same products; since the default form shares operand
-    # fragments between a wave's two output rows it adds the 25 taps dx-major, the persistent one dy-major: equal to
-    # fp32 rounding, and as close to fp64 as the default
-    monkey = k._CONV_PERSISTENT
-    try:
-        k._CONV_PERSISTENT = not monkey
-        other = k.conv5x5_dec_f16x3(x.to(DEV), wf, b.to(DEV), relu=True)
-    finally:
-        k._CONV_PERSISTENT = monkey
-    assert (other - got).abs().max().item() < 2e-6 * scale
-    assert (other.cpu().double() - ref).abs().max().item() < max(2.5 * err32, 2e-6 * scale)
     # pass-major input / output: same values, other layout
     xpm = _to_pass_major(x).to(DEV)
     for pm_in, pm_out in ((True, False), (False, True), (True, True)):
@@ -721,87 +710,22 @@ def test_f16_operand_planes_from_producers(M):
     assert (a - bb).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("M,N,Kd", [(38400, 512, 512), (12000, 1536, 512), (9000, 512, 2048)])
-def test_planes_gemm_persistent_phases_and_stream_k(M, N, Kd, monkeypatch):
-    """
-    tocvp_gemm_f16planes(_ws)_f32, round-3 persistent kernel (gemm_f16p.hip, planes3):
-      * the default plan cuts the rows into phases of 256- / 128- / 64-row tiles (38400 x 512: 256 + 176 tiles; the
-        other shapes end in a ragged row block): every row against an fp64 reference of the SAME fp16 planes
-        (what is tested is the kernel, not the split), bias + ReLU + residual epilogue, fp32 and plane outputs;
-      * stream-K through the workspace entry point (forced: TOCVP_GEMM_P3_SK is read once per process, so the
-        kernel is reached through the environment of a fresh interpreter in scripts; here the data-parallel plan
-        and the workspace entry point must agree bit for bit when stream-K is not selected) and a second launch on
-        the same workspace reproduces the first bit for bit.
-    """
-    import ctypes
-    k = _k()
-    monkeypatch.setattr(k, "_GEMM_P2", True)                    # the persistent planes kernel is opt-in
-    monkeypatch.setattr(k, "_GEMM_P2_MIN_ROWS", 1)              # every plane-input product on the planes kernel
-    monkeypatch.setattr(k, "_GEMM_CHUNK", False)                # (not on the round-4 chunk-resident kernels)
-    monkeypatch.setattr(k, "_GEMM_MID", False)
-    x = rnd("p3x", (M, Kd), "normal")
-    w = rnd("p3w", (N, Kd), "uniform", Kd ** -0.5)
-    b = rnd("p3b", (N,), "uniform", 0.1)
-    r = rnd("p3r", (M, N), "normal")
-    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
-    with k.gemm_precision("f16x3"):
-        xp = k.linear(xd, torch.eye(Kd, device=DEV), out_split=22)            # the activation as fp16 planes
-        got = k.linear(xp, wd, bd, act=k.ACT_RELU, residual=rd)
-        got_planes = k.linear(xp, wd, bd, act=k.ACT_RELU, out_split=22)
-    # fp64 reference from the planes themselves (values 2^-8 (hi + lo)) and the fp16 weight planes (2^-10 (hi + lo))
-    a64 = xp.planes.double().sum(dim=1) / 256.0
-    wpl = k._split_weight(wd, 22, frag="rows")
-    w64 = wpl.double().sum(dim=1) / 1024.0
-    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2 - 150, M // 2 + 150), torch.arange(M - 300, M)]).to(DEV)
-    ref = torch.relu(a64[rows] @ w64.t() + bd.double()) + rd[rows].double()
-    err = (got[rows].double() - ref).abs().max().item()
-    rebuilt = got_planes.planes.double().sum(dim=1) / 256.0
-    err_p = (rebuilt[rows] - (ref - rd[rows].double())).abs().max().item()
-    print(f"planes3 {M}x{N}x{Kd}: |fp32 out - fp64| {err:.2e}, |plane out - fp64| {err_p:.2e}")
-    assert err < 3e-6 * max(1.0, float(ref.abs().max())) and err_p < 3e-6 * max(1.0, float(ref.abs().max()))
-    # the whole output against the same product computed in row chunks small enough for one phase each
-    chunks = torch.cat([k.linear(k.SplitAct(xp.planes[i:i + 3000].contiguous(), (min(3000, M - i), Kd)), wd, bd,
-                                 act=k.ACT_RELU, residual=rd[i:i + 3000].contiguous(), precision="f16x3")
-                        for i in range(0, M, 3000)])
-    assert torch.equal(chunks, got), "the result must not depend on the cut into phases"
-    # workspace entry point: same plan, same bits; and it leaves its workspace re-armed (second launch identical)
-    lib = k.lib()
-    nbytes = lib.tocvp_gemm_f16planes_ws_bytes()
-    ws = torch.zeros((nbytes + 3) // 4, device=DEV, dtype=torch.int32)
-    outs = []
-    for _ in range(2):
-        o = torch.empty((M, N), device=DEV, dtype=torch.float32)
-        rc = lib.tocvp_gemm_f16planes_ws_f32(xp.planes.data_ptr(), wpl.data_ptr(), bd.data_ptr(), rd.data_ptr(), N,
-                                             o.data_ptr(), 0, N, M, N, Kd, int(k.ACT_RELU), ws.data_ptr(),
-                                             ctypes.c_size_t(nbytes), torch.cuda.current_stream().cuda_stream)
-        assert rc == 0
-        outs.append(o)
-    torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
-    assert (outs[0] - got).abs().max().item() < 2e-5 * max(1.0, float(got.abs().max()))
-    assert int(ws[:1024].abs().sum()) == 0, "flag words must be zero again after the launch"
-
-
 @pytest.mark.parametrize("B,Tq,Lt", [(3, 300, 12), (2, 37, 5), (1, 30, 16), (61, 270, 12), (130, 140, 9),
-                                     (2, 70, 17), (3, 300, 24), (40, 290, 32), (130, 100, 29),
-                                     (2, 70, 33), (3, 300, 40), (40, 290, 50), (5, 37, 64)])
+                                     (2, 70, 17), (3, 300, 24), (40, 290, 32), (130, 100, 29)])
 def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt, monkeypatch):
     """
     csrc/xattn.hip: LayerNorm + q projection + attention over the caption + output projection + residual in ONE
     kernel, with the projections folded into per-sample caption operands.  Against (a) an fp64 evaluation of the
     reference's TransformerDecoderBlock cross-attention half (attention.py:445-463, 303-319) and (b) this repo's
     four-kernel path on the same module (TextKV without collapsed operands); ragged Tq, Lt < 16 (masked slots).
-    Captions of 17-32 tokens (round 4) take 32 caption slots per head (xattn_collapsed_kernel<32>, any batch size),
-    33-64 tokens (the text encoder admits 50, text_encoders.py:36) 64 slots per head (xattn_collapsed_kernel<64>: two
-    score tiles per head and wave, one workgroup per CU).
+    Captions of 17-32 tokens (round 4) take 32 caption slots per head (xattn_collapsed_kernel<32>, any batch size);
+    33-50 tokens (the text encoder admits 50, text_encoders.py:36) keep the four-kernel path (checked at the end).
     The last two shapes fill the chip and take the 64-token-workgroup variant (B not a multiple of 8: idle ids of the
     XCD-aware numbering; Tq not a multiple of 64), the first three the 32-token variant.
     """
     from textocvp_amd.models.Blocks import attention as A
     from textocvp_amd.models.Blocks.attention import TextKV, TransformerDecoderBlock
     k = _k()
-    if Lt > 32:                                                    # the 64-slot form is opt-in (TOCVP_XATTN_MAX_LT=64)
-        monkeypatch.setattr(A, "_XATTN_MAX_LT", 64)
     E, H, dh = 512, 8, 64
     blk = TransformerDecoderBlock(embed_dim=E, head_dim=dh, kv_dim=E, num_heads=H, mlp_size=2048).eval()
     with torch.no_grad():
@@ -842,10 +766,9 @@ def test_cross_attention_collapsed_over_the_caption(B, Tq, Lt, monkeypatch):
     assert err < 5e-6 * max(1.0, float(z_ref.abs().max())) and err < 3 * err4 + 2e-6
     assert (full - full4).abs().max().item() < 2e-5
     assert torch.isfinite(z).all()
-    # captions behind the limit fall back to the four-kernel path (default limit 32: the 64-slot form is opt-in)
+    # captions behind the limit (32 tokens) fall back to the four-kernel path
     with torch.no_grad(), k.gemm_precision("f16x3"):
-        assert blk.project_text(rnd("xa.long", (B, 65, E), "normal").to(DEV)).collapsed is None
-        monkeypatch.setattr(A, "_XATTN_MAX_LT", 32)
+        assert blk.project_text(rnd("xa.long", (B, 50, E), "normal").to(DEV)).collapsed is None
         assert blk.project_text(rnd("xa.long", (B, 33, E), "normal").to(DEV)).collapsed is None
 
 
@@ -1086,9 +1009,8 @@ def test_gemm_chunk_mid_size_form(M, N, Kd, monkeypatch):
     """
     tocvp_gemm_f16mid_f32 (csrc/gemm_f16c.hip, mid-size form: 64 x 256 tiles, two workgroups per CU, A chunks by LDS-DMA,
     weights streamed) -- the predictor's products at small evaluation batches (reference attention.py:167-175, 355-359,
-    428-432).  Without split-K BIT-IDENTICAL to tocvp_gemm_bf16wfrag_f32 on the same planes (every activation, residual,
-    plane output, ragged rows); with split-K through the workspace: repeatable bit for bit, fp32-class against float64, the
-    arrival counters end at zero.
+    428-432).  BIT-IDENTICAL to tocvp_gemm_bf16wfrag_f32 on the same planes (every activation, residual, plane output,
+    ragged rows), repeatable, fp32-class against float64.
     """
     k = _k()
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -1108,22 +1030,15 @@ def test_gemm_chunk_mid_size_form(M, N, Kd, monkeypatch):
                 monkeypatch.setattr(k, "_GEMM_MID", False)
                 a = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
                 monkeypatch.setattr(k, "_GEMM_MID", True)
-                monkeypatch.setattr(k, "_GEMM_MID_SPLITK", False)
                 c = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
-                monkeypatch.setattr(k, "_GEMM_MID_SPLITK", True)
-                d1 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
-                d2 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
+                c2 = k.linear(xp, wd, bd, act=act, residual=res, out_split=osplit)
                 if osplit:
-                    a, c, d1, d2 = (t.planes.view(torch.int16) for t in (a, c, d1, d2))
+                    a, c, c2 = (t.planes.view(torch.int16) for t in (a, c, c2))
                 assert torch.equal(a, c), (act, res is not None, osplit)
-                assert torch.equal(d1, d2)
-                if not osplit:
-                    assert (d1 - a).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+                assert torch.equal(c, c2)
         got = k.linear(xp, wd, bd)
     err = (got.cpu().double() - ref).abs().max().item()
     assert err < 5e-6 * max(1.0, ref.abs().max().item())
-    wk = k._mid_workspace(xd.device, torch.cuda.current_stream().cuda_stream)[0]
-    assert int(wk[:4096].view(torch.int32).abs().sum()) == 0
 
 
 @pytest.mark.parametrize("B,H,T,dh", [(24, 12, 257, 64), (70, 4, 129, 32)])

@@ -449,23 +449,13 @@ static int mha_launch(const float* Q, int ldq, const float* K, int ldk, const fl
         (Osplit && !tocvp_aligned16(Osplit)))
         return TOCVP_EALIGN;
     if (B == 0) return TOCVP_OK;
-    static const int xcd = []() { const char* e = getenv("TOCVP_MHA_XCD"); return e ? atoi(e) : 1; }();
+    const int xcd = 1;                             // XCD-aware workgroup ids (the A/B switch TOCVP_MHA_XCD of round 3 is gone)
     TOCVP_CHECK_ARG(tq_tot == 0 || (tq_tot >= Tq && bias == nullptr));
     MhaArgs p{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, scale, key_len, Osplit, nsplit, bias, xcd, tq_tot ? tq_tot : Tq};
-    // 64-query workgroups (TOCVP_MHA_NW=2) leave fewer empty query slots (300 tokens: 320 against 384) but measured
-    // SLOWER in the rollout, 245 against 194 us at 128 x 8 x 300 x 300 (two A/B rounds on one box): 176 registers
-    // -> two waves per SIMD instead of three, and every workgroup stages (splits, transposes) the same K / V tiles for
-    // half as many queries.  128-query workgroups stay the default.
-    static const int nw_env = []() { const char* e = getenv("TOCVP_MHA_NW"); return e ? atoi(e) : 0; }();
-    const int nw = nw_env == 2 ? 2 : 4;
-    const int qb = 32 * nw;
-    dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + qb - 1) / qb)));
+    // (64-query workgroups -- NW = 2 -- were built in round 4, measured slower (245 vs 194 us at 128 x 8 x 300 x 300) and retired)
+    const dim3 grid((unsigned)((size_t)(((long)B * H + 7) / 8) * 8 * ((Tq + 127) / 128)));
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define TOCVP_MHA_GO(DH_, QK_)                                                                              \
-    do {                                                                                                    \
-        if (nw == 2) hipLaunchKernelGGL((mha_f32_kernel<DH_, QK_, 2>), grid, dim3(128), 0, s, p);           \
-        else hipLaunchKernelGGL((mha_f32_kernel<DH_, QK_, 4>), grid, dim3(256), 0, s, p);                   \
-    } while (0)
+#define TOCVP_MHA_GO(DH_, QK_) hipLaunchKernelGGL((mha_f32_kernel<DH_, QK_, 4>), grid, dim3(256), 0, s, p)
     if (dh == 64) {
         if (qk16) TOCVP_MHA_GO(64, true);
         else TOCVP_MHA_GO(64, false);

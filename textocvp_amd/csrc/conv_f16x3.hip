@@ -608,258 +608,6 @@ __global__ __launch_bounds__(256, 2) void conv5x5_dec_f16x3_kernel(Args p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// v2 ("persistent"): the same arithmetic, tile and LDS image, but ONE workgroup per CU (one wave per
-// SIMD, up to 512 registers per lane) that walks its tiles and never stops the matrix cores for staging:
-//   * two LDS halo images; while pass s (16 input channels, 25 taps, 600 MFMAs per wave) is multiplied out
-//     of one, the halo of pass s + 1 -- the next 16 channels, or pass 0 of the workgroup's NEXT tile -- is
-//     loaded (13 x 16 B per thread, all issued at tap 0), converted to fp16 planes and written into the
-//     other in the gaps between the MFMAs (item i at tap 5 + i);  one barrier per pass;
-//   * weight fragments are fetched FOUR taps ahead (5 rotating register sets): vmcnt retires in order, so
-//     a fragment requested behind the halo loads (HBM latency) must not be needed before they are back;
-//   * A fragments of tap t + 1 are read from LDS while tap t multiplies (2 register sets);
-//   * the accumulators are written once per tile through the image that pass 3 just released.
-// v1 (two workgroups per CU taking turns) leaves the matrix pipe idle ~27 % of the time: staging phases of
-// both workgroups overlap now and then, and each pass starts with cold operand reads.
-// ------------------------------------------------------------------------------------------------
-template <int MODE, bool PM_IN>
-__global__ __launch_bounds__(256, 1) void conv5x5_dec_f16x3_persistent_kernel(Args p, int ntiles_total) {
-    constexpr int NT = 256;
-    constexpr int IMG = IH * IW * ROWB;                              // 65280 B per halo image
-    constexpr int SS = C + 4;                                        // padded floats per staged pixel
-    constexpr int ITEMS = IH * IW * (CCH / 4);                       // f32x4 items per pass
-    constexpr int NITEM = (ITEMS + NT - 1) / NT;                     // 13 per thread
-    // staging rounds: all loads of a round are issued at one tap, item i of the round is converted LAG + i taps
-    // later.  Layer-1 mode loads two values per item (cpos + S): two rounds of 7 + 6 items halve the registers.
-    constexpr int NROUND = MODE == 1 ? 2 : 1, RI = (NITEM + NROUND - 1) / NROUND, LAG = 5, ROUND_TAPS = 12;
-    static_assert((NROUND - 1) * ROUND_TAPS + LAG + RI <= NTAP, "staging must finish inside the pass");
-    static_assert(LAG + RI <= ROUND_TAPS || NROUND == 1, "a round's registers are free before the next round");
-    static_assert(4 * 32 * SS * 4 <= IMG, "epilogue stage must fit the released image");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IMG];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int tiles_x = p.W / TW, tiles_per_img = tiles_x * (p.H / TH);
-
-    // XCD-contiguous tile order: workgroups g and g + 8 share an XCD (round-robin dispatch), so XCD x walks the
-    // contiguous range [x * per, (x + 1) * per): vertically adjacent tiles (shared halo rows) meet in one L2.
-    const int G = gridDim.x, g = blockIdx.x;
-    const int per = (ntiles_total + 7) / 8;
-    auto tile_of = [&](int k) -> int {                               // k-th tile of this workgroup, -1 = none
-        const int L = g + k * G;                                     // logical id, L % 8 = XCD group
-        const int ph = (L & 7) * per + (L >> 3);
-        return ((L >> 3) < per && ph < ntiles_total) ? ph : -1;
-    };
-    int nmine = 0;
-    while (tile_of(nmine) >= 0) ++nmine;
-    if (nmine == 0) return;
-
-    // per-thread staging items: pixel (row, column) inside the halo tile; the one item beyond the image (upper
-    // threads only) is aimed at the 16 unused pad bytes of the last pixel, so the tap loop has no branch
-    const int pix0 = t >> 2, c4 = (t & 3) * 4;
-    int prow[NITEM], pcol[NITEM], st_off[NITEM];
-#pragma unroll
-    for (int j = 0; j < NITEM; ++j) {
-        const bool ok = (t + j * NT) < ITEMS;
-        const int pix = ok ? pix0 + 64 * j : IH * IW - 1;
-        prow[j] = pix / IW;
-        pcol[j] = pix - prow[j] * IW;
-        st_off[j] = pix * ROWB + (ok ? c4 * 2 : 64);
-    }
-    const int lo_last = (t + (NITEM - 1) * NT) < ITEMS ? OFF_LO : 8;     // the dummy's lo half stays inside the pad too
-
-    // geometry of a tile: image base pointers and the tile origin, all scalar
-    struct Geo { const char* xb; const char* ab; int ty0, tx0; };
-    auto geo_of = [&](int tile) -> Geo {
-        const int img = tile / tiles_per_img, tl = tile - img * tiles_per_img;
-        Geo gg;
-        gg.xb = reinterpret_cast<const char*>(MODE == 0 ? p.x + (size_t)img * p.H * p.W * C : p.x);
-        gg.ab = reinterpret_cast<const char*>(MODE == 1 ? p.aux + (size_t)img * 25 * C : p.x);
-        gg.ty0 = (tl / tiles_x) * TH;
-        gg.tx0 = (tl % tiles_x) * TW;
-        return gg;
-    };
-
-    // staging registers of the round in flight
-    f32x4 tv[RI];
-    f32x4 ts[MODE == 1 ? RI : 1];
-    auto stage_issue = [&](const Geo& gg, int pass, int round) {     // all loads of one round, back to back
-#pragma unroll
-        for (int jj = 0; jj < RI; ++jj) {
-            const int j = round * RI + jj;
-            if (j >= NITEM) break;
-            const int iy = min(max(gg.ty0 + prow[j] - 2, 0), p.H - 1);
-            const int ix = min(max(gg.tx0 + pcol[j] - 2, 0), p.W - 1);
-            const int c = pass * CCH + c4;
-            const unsigned off = PM_IN ? (unsigned)(((pass * p.H + iy) * p.W + ix) * CCH + c4) * 4u
-                                       : (unsigned)((iy * p.W + ix) * C + c) * 4u;
-            tv[jj] = *reinterpret_cast<const f32x4*>(gg.xb + off);
-            if (MODE == 1) {
-                const int cls = border_class(iy, p.H) * 5 + border_class(ix, p.W);
-                ts[jj] = *reinterpret_cast<const f32x4*>(gg.ab + (unsigned)(cls * C + c) * 4u);
-            }
-        }
-    };
-    auto stage_convert = [&](const Geo& gg, int j, unsigned char* img_dst) {
-        const int iy = gg.ty0 + prow[j] - 2, ix = gg.tx0 + pcol[j] - 2;
-        const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        f32x4 v = tv[j % RI];
-        if (MODE == 1) {
-            v += ts[j % RI];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-        }
-        f16x4 hi, lo;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float X = inside ? clampf(v[u] * SA, F16MAX) : 0.f;
-            hi[u] = (_Float16)X;
-            lo[u] = (_Float16)(X - (float)hi[u]);
-        }
-        unsigned char* dst = img_dst + st_off[j];
-        *reinterpret_cast<f16x4*>(dst) = hi;
-        *reinterpret_cast<f16x4*>(dst + (j == NITEM - 1 ? lo_last : OFF_LO)) = lo;
-    };
-
-    // weight fragments [plane][nb] of tap q (0 .. 99, wraps into the next tile), 5 rotating sets
-    f16x8 bw[5][2][2];
-    auto load_w = [&](int set, int q) {
-        const unsigned char* base = p.wf + (size_t)(q >= NPASS * NTAP ? q - NPASS * NTAP : q) * TAP_BYTES + lane * 16;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                bw[set][pl][n] = *reinterpret_cast<const f16x8*>(base + (pl * 2 + n) * FRAG);
-    };
-
-    int a_off[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) a_off[m] = ((2 * wave + (m >> 1)) * IW + (m & 1) * 32 + l31) * ROWB + h * 16;
-    f16x8 ah[2][4], al[2][4];
-    auto load_a = [&](int set, const unsigned char* img_src, int tap) {
-        const unsigned char* a_base = img_src + ((tap / 5) * IW + (tap % 5)) * ROWB;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            ah[set][m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m]);
-            al[set][m] = *reinterpret_cast<const f16x8*>(a_base + a_off[m] + OFF_LO);
-        }
-    };
-
-    // ---- prologue: halo of (tile 0, pass 0) into image 0, weights of taps 0..3
-    Geo cur_geo = geo_of(tile_of(0));
-#pragma unroll
-    for (int r = 0; r < NROUND; ++r) {
-        stage_issue(cur_geo, 0, r);
-#pragma unroll
-        for (int jj = 0; jj < RI; ++jj)
-            if (r * RI + jj < NITEM) stage_convert(cur_geo, r * RI + jj, lds);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) load_w(q, q);
-    __syncthreads();
-
-    for (int k = 0; k < nmine; ++k) {
-        // the tile after this one (the last tile stages itself once more: a harmless dummy, no branch in the loop)
-        const Geo next_geo = geo_of(tile_of(k + 1 < nmine ? k + 1 : k));
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
-
-        for (int pass = 0; pass < NPASS; ++pass) {                  // pass p multiplies out of image p & 1
-            const unsigned char* cur = lds + (pass & 1) * IMG;
-            unsigned char* nxt = lds + ((pass + 1) & 1) * IMG;
-            Geo sg;                                                  // what is staged behind this pass
-            sg.xb = pass == NPASS - 1 ? next_geo.xb : cur_geo.xb;
-            sg.ab = pass == NPASS - 1 ? next_geo.ab : cur_geo.ab;
-            sg.ty0 = pass == NPASS - 1 ? next_geo.ty0 : cur_geo.ty0;
-            sg.tx0 = pass == NPASS - 1 ? next_geo.tx0 : cur_geo.tx0;
-            const int spass = (pass + 1) & 3;
-            load_a(0, cur, 0);
-#pragma unroll
-            for (int tap = 0; tap < NTAP; ++tap) {
-                // issue section: everything that is consumed one or more taps LATER.  Pinned in front of this tap's
-                // MFMAs (one wave per SIMD: an operand read that the scheduler sinks next to its use stalls the pipe)
-                if (ABL != 5 && tap % ROUND_TAPS == 0 && tap / ROUND_TAPS < NROUND)
-                    stage_issue(sg, spass, tap / ROUND_TAPS);
-                if (ABL != 1) load_w((tap + 4) % 5, pass * NTAP + tap + 4);        // four taps ahead
-                if (ABL != 4 && tap + 1 < NTAP) load_a((tap + 1) & 1, cur, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ABL != 5) {
-                    const int r = tap / ROUND_TAPS < NROUND ? tap / ROUND_TAPS : NROUND - 1;
-                    const int jj = tap - r * ROUND_TAPS - LAG;
-                    if (jj >= 0 && jj < RI && r * RI + jj < NITEM) stage_convert(sg, r * RI + jj, nxt);
-                }
-                const int cs = tap % 5, as = tap & 1;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        if (ABL == 7) {                                               // keep the operands alive
-                            asm volatile("" :: "v"(al[as][m]), "v"(ah[as][m]), "v"(bw[cs][0][n]), "v"(bw[cs][1][n]));
-                            continue;
-                        }
-                        acc[m][n] = mfma16(al[as][m], bw[cs][0][n], acc[m][n]);      // Xl Wh
-                        acc[m][n] = mfma16(ah[as][m], bw[cs][1][n], acc[m][n]);      // Xh Wl
-                        acc[m][n] = mfma16(ah[as][m], bw[cs][0][n], acc[m][n]);      // Xh Wh
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();                    // `nxt` is complete, `cur` is released
-        }
-
-        // ---- tile epilogue through image 1 (released by pass 3; image 0 already holds the next tile's pass 0):
-        //      one 32-pixel x 64-channel block at a time, every store instruction writes 1 KiB of contiguous output
-        {
-            const int tile = tile_of(k);
-            const int img = tile / tiles_per_img;
-            float* stage = reinterpret_cast<float*>(lds + IMG) + wave * (32 * SS);
-            constexpr float UNSCALE = 1.f / (SA * SW);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const float bv = p.bias[n * 32 + l31];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[m][n][r] * UNSCALE + bv;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        stage[acc_row(r, h) * SS + n * 32 + l31] = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int oy = cur_geo.ty0 + 2 * wave + (m >> 1), ox = cur_geo.tx0 + (m & 1) * 32;
-                if (p.pm_out) {
-                    float* ybase = p.y + (size_t)img * p.H * p.W * C;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int plane = it >> 1, px = (it & 1) * 16 + (lane >> 2), cq = (lane & 3) * 4;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
-                        if (ABL != 8 || v[0] == 12345.f)
-                            *reinterpret_cast<f32x4*>(ybase + (((size_t)plane * p.H + oy) * p.W + ox + px) * CCH + cq) = v;
-                    }
-                } else {
-                    float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + ox) * C;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = lane + 64 * it;
-                        const int px = idx >> 4, cc = (idx & 15) * 4;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + cc);
-                        if (ABL != 8 || v[0] == 12345.f) *reinterpret_cast<f32x4*>(yrow + (size_t)px * C + cc) = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();                        // image 1 is staged again behind the next tile's pass 0
-        cur_geo = next_geo;
-    }
-}
-
 // (64, 64, 5, 5) fp32 -> wf: [pass(4)][tap(25)][plane(Wh, Wl)][nb(2)][lane(64)][8 f16]
 // lane (c = l & 31, hh = l >> 5): output channel nb*32 + c, input channels pass*16 + 8 hh + j of the tap.
 __global__ __launch_bounds__(256) void split_conv_weights_dec_f16x3_kernel(const float* __restrict__ w,
@@ -978,10 +726,11 @@ extern "C" int tocvp_split_conv_weights_dec_f16x3(const float* w, void* wf, int 
 extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf,
                                            const float* bias, float* y, int nimg, int H, int W, int Cin,
                                            int Cout, int relu, int layout, void* stream) {
-    // layout: bit 0 pass-major input, bit 1 pass-major output, bit 2 persistent form, bit 3 the pass-major buffers hold
-    // operand planes (written by / read from a neighbouring layer of this kernel; not with the persistent form)
-    TOCVP_CHECK_ARG(layout >= 0 && layout <= 15 && !(in_mode == 1 && (layout & 1)));
-    TOCVP_CHECK_ARG(!(layout & 8) || ((layout & 3) != 0 && !(layout & 4)));
+    // layout: bit 0 pass-major input, bit 1 pass-major output, bit 3 the pass-major buffers hold operand planes (written by /
+    // read from a neighbouring layer of this kernel); bit 2 (the persistent form of rounds 2-4, retired in round 5: it
+    // measured the same as this kernel) is refused
+    TOCVP_CHECK_ARG(layout >= 0 && layout <= 15 && !(layout & 4) && !(in_mode == 1 && (layout & 1)));
+    TOCVP_CHECK_ARG(!(layout & 8) || (layout & 3) != 0);
     // planes input: the DMA source offsets are kept as 16-bit counts of 16-byte pieces inside one pass plane
     TOCVP_CHECK_ARG((layout & 9) != 9 || (long)H * W <= 16384);
     TOCVP_CHECK_ARG(x && wf && bias && y);
@@ -998,24 +747,6 @@ extern "C" int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int
            (layout & 2) ? ((layout & 8) ? 2 : 1) : 0};
     const int ntiles = (int)((size_t)nimg * (H / TH) * (W / TW));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (layout & 4) {
-        // persistent form: one workgroup per CU walks its tiles (bit 2 of `layout`)
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return TOCVP_ELAUNCH;
-            ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-        const dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu));
-        if (in_mode == 1)
-            hipLaunchKernelGGL((conv5x5_dec_f16x3_persistent_kernel<1, false>), grid, dim3(256), 0, s, a, ntiles);
-        else if (layout & 1)
-            hipLaunchKernelGGL((conv5x5_dec_f16x3_persistent_kernel<0, true>), grid, dim3(256), 0, s, a, ntiles);
-        else
-            hipLaunchKernelGGL((conv5x5_dec_f16x3_persistent_kernel<0, false>), grid, dim3(256), 0, s, a, ntiles);
-        return tocvp_launch_status();
-    }
 #if TOCVP_CONV_XCD
     const dim3 grid((unsigned)((size_t)((nimg + 7) / 8) * 8 * (H / TH) * (W / TW)));
 #else

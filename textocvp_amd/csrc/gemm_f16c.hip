@@ -390,15 +390,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_chunk_kernel(ChunkArgs p) {
 constexpr int MBM = 64;                      // rows per workgroup
 constexpr int MBN = 256;                     // outputs per workgroup
 constexpr int MABYTES = MBM * AROW;          // 32 KB chunk image
-constexpr int MREC = MBM * MBN;              // floats per parked record (64 KB)
-constexpr int MID_CTR_BYTES = 16384;         // 4096 tile counters
-constexpr int MID_RECORDS = 1024;            // 64 MB of records
 
 struct MidArgs {
     const unsigned char* A; const unsigned char* Wf; const float* bias; const float* R; int ldr;
     void* C; int ldc; int c_split;
-    int M, N, K, col_tiles, S;
-    float* ws_part; unsigned* ws_ctr;
+    int M, N, K, col_tiles;
     int row_tiles, xcd_rows;
 };
 
@@ -422,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
         slice = 0;
         tile = rt * p.col_tiles + ct;
     } else {
-        slice = (int)blockIdx.x % p.S;
-        tile = (int)blockIdx.x / p.S;
+        slice = 0;
+        tile = (int)blockIdx.x;
         rt = tile / p.col_tiles;
         ct = tile % p.col_tiles;
     }
@@ -431,7 +427,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int KS = p.K / 16, nchunk = p.K / CK;
-    const int c0 = nchunk * slice / p.S, c1 = nchunk * (slice + 1) / p.S;      // chunk range of this slice (never empty: S <= nchunk)
+    const int c0 = 0, c1 = nchunk;                                   // (split-K over chunk ranges was built, measured slower and retired)
+    (void)slice;
     const int m0 = rt * MBM, n0 = ct * MBN;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned x15 = (unsigned)(l31 & 15);
@@ -536,60 +533,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_mid_kernel(MidArgs p) {
         oth = t_;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the fragment loads past the end
-
-    // ---- split K: park, count in, the last arriver adds the slices in slice order
-    if (p.S > 1) {
-        {
-            // write-through (sc1) 16-byte stores: the record leaves the XCD's L2 as it is written, so no release fence is
-            // needed in front of the arrival count (its L2 write-back cost ~6.5 us per workgroup in gemm_bf16.hip's split-K,
-            // and 23 us on a two-slice 2400 x 1536 x 512 launch here)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ws_part, 0, MID_RECORDS * MREC * 4, 0x00020000);
-            const unsigned off0 = (unsigned)((((size_t)tile * p.S + slice) * MREC + ((size_t)w * 64 * 16 + lane) * 4) * sizeof(float));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
-                                                               off0 + ((i * 2 + j) * 4 + g) * 1024, 0, 16);
-                    }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its stores
-        __syncthreads();
-        unsigned* arrived = reinterpret_cast<unsigned*>(lds);        // the chunk images are dead
-        if (t == 0) {
-            const unsigned old = __hip_atomic_fetch_add(p.ws_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)(p.S - 1)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.ws_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-            }
-            *arrived = old;
-        }
-        __syncthreads();
-        if (*arrived != (unsigned)(p.S - 1)) return;
-        __syncthreads();                                             // everyone has read the flag before LDS is reused
-        const float* rec0 = p.ws_part + (size_t)tile * p.S * MREC + ((size_t)w * 64 * 16 + lane) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll 1
-        for (int sl = 0; sl < p.S; ++sl) {
-            f32x4 v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = *reinterpret_cast<const f32x4*>(rec0 + (size_t)sl * MREC + e * 256);
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[e >> 3][(e >> 2) & 1][4 * (e & 3) + u] += v[e][u];
-        }
-    }
 
     // ---- epilogue: register quad g of acc[i][j] = outputs n0 + 64 w + 32 j + 8 g + 4 h .. + 3 of row 32 i + l31; 64 rows x
     // 256 floats through LDS (row = 64 chunks of 16 B, physical chunk = logical ^ (row & 15)); a lane writes out the same
@@ -706,38 +649,23 @@ extern "C" int tocvp_gemm_f16chunk_f32(const void* A_planes, const void* W_frag,
     return tocvp_launch_status();
 }
 
-extern "C" size_t tocvp_gemm_f16mid_ws_bytes(void) { return (size_t)MID_CTR_BYTES + (size_t)MID_RECORDS * MREC * sizeof(float); }
-
 extern "C" int tocvp_gemm_f16mid_f32(const void* A_planes, const void* W_frag, const float* bias, const float* R, int ldr,
-                                     void* C, int c_split, int ldc, int M, int N, int K, int act, void* ws, size_t ws_bytes,
-                                     void* stream) {
+                                     void* C, int c_split, int ldc, int M, int N, int K, int act, void* stream) {
     TOCVP_CHECK_ARG(A_planes && W_frag && C && M >= 0 && N > 0 && K > 0);
     TOCVP_CHECK_ARG((N % MBN) == 0 && (K % CK) == 0);
     TOCVP_CHECK_ARG(act >= TOCVP_ACT_NONE && act <= TOCVP_ACT_GELU);
     TOCVP_CHECK_ARG(c_split || (ldc >= N && (ldc & 3) == 0));
     TOCVP_CHECK_ARG(R == nullptr || (ldr >= N && (ldr & 3) == 0));
     TOCVP_CHECK_ARG((size_t)M * 2 * K * 2 < 0xffffffffull);
-    TOCVP_CHECK_ARG(ws == nullptr || (ws_bytes >= tocvp_gemm_f16mid_ws_bytes() && tocvp_aligned16(ws)));
     if (!tocvp_aligned16(A_planes) || !tocvp_aligned16(W_frag) || !tocvp_aligned16(C) || (bias && !tocvp_aligned16(bias)) ||
         (R && !tocvp_aligned16(R)))
         return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
     const int row_tiles = (M + MBM - 1) / MBM, col_tiles = N / MBN, tiles = row_tiles * col_tiles, nchunk = K / CK;
-    // slices of K while the workgroups fit the chip's 2 x CUs slots, every slice at least two chunks deep
-    int S = 1;
-    if (ws) {
-        static const int smax = []() { const char* e = getenv("TOCVP_GEMM_MID_SMAX"); return e ? atoi(e) : 8; }();
-        while (2 * S <= smax && tiles * 2 * S <= 2 * gc_cus() && nchunk / (2 * S) >= 2 && tiles * 2 * S <= MID_RECORDS &&
-               tiles <= MID_CTR_BYTES / 4)
-            S *= 2;
-    }
     MidArgs p{static_cast<const unsigned char*>(A_planes), static_cast<const unsigned char*>(W_frag), bias, R, ldr, C, ldc,
-              c_split, M, N, K, col_tiles, S,
-              ws ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + MID_CTR_BYTES) : nullptr,
-              static_cast<unsigned*>(ws), row_tiles, 0};
-    static const bool xcd_on = []() { const char* e = getenv("TOCVP_GEMM_MID_XCD"); return !e || atoi(e) != 0; }();
-    unsigned nwg = (unsigned)(tiles * S);
-    if (S == 1 && xcd_on && col_tiles > 1) {
+              c_split, M, N, K, col_tiles, row_tiles, 0};
+    unsigned nwg = (unsigned)tiles;
+    if (col_tiles > 1) {
         p.xcd_rows = 1;
         nwg = (unsigned)(((row_tiles + 7) / 8) * 8 * col_tiles);
     }

@@ -64,7 +64,6 @@ struct MlpArgs {
     // zig-zag: odd hidden chunks walk the X k-tiles (and W1's) from the last to the first -- the 32 X images of an XCD (8 MB)
     // cycle through its 4 MB L2 once per chunk, front to back every time = no hits under LRU; turning round at the end of a
     // chunk finds the most recent half still there.  Other accumulation order in those chunks: not the default (TOCVP_MLP_ZIGZAG)
-    int zz;                                  // (selects the instantiation; not read by the kernel)
 };
 constexpr int REC = BM * ME;                 // floats per parked accumulator record (256 KB)
 constexpr int WS_CTR_BYTES = 4096;           // 1024 counters
@@ -140,7 +139,7 @@ __device__ __forceinline__ void weave() {
     if (NM - PER * SLOTS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * SLOTS, 0);
 }
 
-template <bool HASR, bool ZZ>
+template <bool HASR>
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NXS * XSTAGE + HBYTES];   // 160 KB: the whole LDS of the CU
     unsigned char* const xs = lds;
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
     // each k-tile's barrier below.  (The hardware still counts these instructions in vmcnt, so the compiler's own counted
     // waits for the weight fragments only ever wait longer than it thinks, never shorter.)
     const unsigned xs_lds = (unsigned)(size_t)xs;                    // LDS byte address of the stage ring
-    auto kphys = [&](int cc, int kt) { return (ZZ && (cc & 1)) ? ME / BK - 1 - kt : kt; };   // physical k-tile of chunk cc
+    auto kphys = [&](int cc, int kt) { return kt; };                 // physical k-tile of chunk cc (a zig-zag order was tried: retired)
     auto dma_x = [&](unsigned stage_off, int kt, int i0 = 0, int i1 = 8) {
         const unsigned char* base = p.X + (size_t)kt * (BK * 2);     // uniform
         asm volatile("" : "+s"(base));          // an SGPR base per call: nothing per-lane and 64-bit is hoisted out of the loop
@@ -579,7 +578,6 @@ extern "C" int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_fr
         return TOCVP_EALIGN;
     if (M == 0) return TOCVP_OK;
     const int tiles = (M + BM - 1) / BM, cus = mlp_cus(), nchunk = Hd / HC;
-    static const int zz = []() { const char* e = getenv("TOCVP_MLP_ZIGZAG"); return e ? atoi(e) : 0; }();
     int n_full = tiles, S = 1;
     const int left = tiles % cus;
     if (ws && left > 0) {
@@ -594,17 +592,10 @@ extern "C" int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_fr
     MlpArgs p{static_cast<const unsigned char*>(x_planes), static_cast<const unsigned char*>(w1_frag), b1,
               static_cast<const unsigned char*>(w2_frag), b2, R, ldr, Y, ldy, M, Hd, n_full, S,
               ws ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + WS_CTR_BYTES) : nullptr,
-              static_cast<unsigned*>(ws), zz};
+              static_cast<unsigned*>(ws)};
     const dim3 grid((unsigned)(n_full + (tiles - n_full) * S));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // the zig-zag order is its own instantiation: as a run-time select it cost the default order ~1 % (address arithmetic in the
-    // DMA and weight-ring issue slots)
-    if (zz) {
-        if (R) hipLaunchKernelGGL((mlp_f16x3_fused_kernel<true, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((mlp_f16x3_fused_kernel<false, true>), grid, dim3(256), 0, s, p);
-    } else {
-        if (R) hipLaunchKernelGGL((mlp_f16x3_fused_kernel<true, false>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((mlp_f16x3_fused_kernel<false, false>), grid, dim3(256), 0, s, p);
-    }
+    if (R) hipLaunchKernelGGL((mlp_f16x3_fused_kernel<true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mlp_f16x3_fused_kernel<false>), grid, dim3(256), 0, s, p);
     return tocvp_launch_status();
 }

@@ -463,7 +463,7 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
                                          const void* Gfrag, const void* Hfrag, const float* bias, float* y, int B,
                                          int Tq, int E_, int heads, int Lt, float scale, void* stream) {
     TOCVP_CHECK_ARG(x && gamma && beta && Gfrag && Hfrag && bias && y);
-    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= 4 * LP);
+    TOCVP_CHECK_ARG(B >= 0 && Tq >= 0 && E_ == E && heads == HEADS && Lt >= 1 && Lt <= 2 * LP);    // 33-64 tokens (the 64-slot form of round 4, equal to the four-kernel path: retired)
     if (!tocvp_aligned16(x) || !tocvp_aligned16(y) || !tocvp_aligned16(gamma) || !tocvp_aligned16(beta) ||
         !tocvp_aligned16(bias) || !tocvp_aligned16(Gfrag) || !tocvp_aligned16(Hfrag))
         return TOCVP_EALIGN;
@@ -476,11 +476,6 @@ extern "C" int tocvp_xattn_collapsed_f32(const float* x, const float* gamma, con
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n;
     }();
-    if (Lt > 2 * LP) {        // 33-64 caption tokens: 64 slots per head
-        hipLaunchKernelGGL(xattn_collapsed_kernel<64>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
-                           static_cast<hipStream_t>(stream), p, gx);
-        return tocvp_launch_status();
-    }
     if (Lt > LP) {            // 17-32 caption tokens: 32 slots per head (operands built with that padding)
         hipLaunchKernelGGL(xattn_collapsed_kernel<32>, dim3((unsigned)(((B + 7) / 8) * 8 * gx)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p, gx);

@@ -51,11 +51,6 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "tocvp_split_weights_planes_f16": (ctypes.c_int, [
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "tocvp_gemm_f16planes_f32": (ctypes.c_int, [
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_tail_taps_f16x3_bytes": (ctypes.c_size_t, []),
     "tocvp_pack_tail_taps_f16x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_conv5x5_dec_f16x3_tail_f32": (ctypes.c_int, [
@@ -84,11 +79,9 @@ _SIGNATURES = {
     "tocvp_conv3x3_up2_f16x3_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "tocvp_gemm_f16mid_ws_bytes": (ctypes.c_size_t, []),
     "tocvp_gemm_f16mid_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
-        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
-        ctypes.c_void_p]),
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tocvp_mha_qk16_rows_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
@@ -119,11 +112,6 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "tocvp_gemm_f16planes_ws_bytes": (ctypes.c_size_t, []),
-    "tocvp_gemm_f16planes_ws_f32": (ctypes.c_int, [
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-        ctypes.c_size_t, ctypes.c_void_p]),
     "tocvp_xattn_collapsed_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -470,39 +458,17 @@ class gemm_precision:
 
 
 _WFRAG = os.environ.get("TOCVP_GEMM_WFRAG", "1") != "0"   # W in MFMA-fragment order (bypasses LDS)
-# all-DMA persistent planes GEMM (gemm_f16p.hip) for plane inputs with N % 256 == 0: opt-in (TOCVP_GEMM_P2=1); by
-# default plane inputs go to the two-workgroups-per-CU planes kernel of gemm_bf16.hip (gemm_f16_planes_kernel; small
-# shapes: the in-loop kernel's ASPLIT form), which shares a CU with the decoder's workgroups
-_GEMM_P2 = os.environ.get("TOCVP_GEMM_P2", "0") != "0"
 # chunk-resident persistent f16x3 GEMM (gemm_f16c.hip) for plane inputs with N % 512 == 0, K % 128 == 0, from
 # _GEMM_CHUNK_MIN_TILES tiles of 128 x 512 up (one workgroup per CU: fewer tiles leave CUs idle and the 64 x 64 / 128 x 128
 # kernels win; 9600 x 512 x 2048 = 75 tiles: 118 vs 103 us, 9600 x 1536 x 512 = 225 tiles: 55 vs 63 us).  TOCVP_GEMM_CHUNK=0: off
 _GEMM_CHUNK = os.environ.get("TOCVP_GEMM_CHUNK", "1") != "0"
 _GEMM_CHUNK_MIN_TILES = int(os.environ.get("TOCVP_GEMM_CHUNK_MIN_TILES", "192"))
-# mid-size form of the chunk kernel (64 x 256 tiles, two workgroups per CU, split-K through a per-stream workspace) for
-# plane-input products of _GEMM_MID_MIN_ROWS .. _GEMM_MID_MAX_ROWS rows (TOCVP_GEMM_MID=0: off)
+# mid-size form of the chunk kernel (64 x 256 tiles, two workgroups per CU) for plane-input products (TOCVP_GEMM_MID=0: off)
 _GEMM_MID = os.environ.get("TOCVP_GEMM_MID", "1") != "0"
 # from _GEMM_MID_MIN_TILES tiles of 64 x 256 (fewer leave CUs idle: 2400 x 512 x 2048 = 76 tiles runs 34.5 us against 31.3 us
-# on the two-operand planes kernel, 2400 x 1536 x 512 = 228 tiles 16.8 against 21.1 us).  Split-K through the workspace is
-# built and deterministic but measured SLOWER than the unsplit launch (2400 x 1536 x 512: 39.7 us with two slices -- the
-# agent-scope release in front of the arrival count), so it is opt-in (TOCVP_GEMM_MID_SPLITK=1)
+# on the two-operand planes kernel, 2400 x 1536 x 512 = 228 tiles 16.8 against 21.1 us); no upper row limit since the
+# XCD-aware tile order (38400 x 1536 x 512 188 vs 207 us against the 256 x 128-tile planes kernel)
 _GEMM_MID_MIN_TILES = int(os.environ.get("TOCVP_GEMM_MID_MIN_TILES", "192"))
-# (no upper row limit since the XCD-aware tile order: 38400 x 1536 x 512 188 vs 207 us, 76800 rows 370 vs 393 us against the
-# 256 x 128-tile planes kernel; B = 128 headline 4041 / 4043 vs 4039 / 4040 frames/s, two alternations)
-_GEMM_MID_MAX_ROWS = int(os.environ.get("TOCVP_GEMM_MID_MAX_ROWS", str(1 << 30)))
-_GEMM_MID_SPLITK = os.environ.get("TOCVP_GEMM_MID_SPLITK", "0") != "0"
-_MID_WS = {}
-
-
-def _mid_workspace(device, stream):
-    key = (device.index, stream)
-    rec = _MID_WS.get(key)
-    if rec is None:
-        nbytes = lib().tocvp_gemm_f16mid_ws_bytes()
-        wk = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
-        rec = _MID_WS[key] = (wk, ctypes.c_void_p(wk.data_ptr()), nbytes)
-    return rec
-_GEMM_P2_MIN_ROWS = int(os.environ.get("TOCVP_GEMM_P2_MIN_ROWS", "4096"))
 # f16x3 pre-scales activations by 2^8 and weights by 2^10 into the fp16 range (gemm_bf16.hip, Elem<true>):
 # fp32-class inside these bounds, saturating outside.  TOCVP_CHECK_RANGE=1 verifies every call (slow: syncs).
 F16X3_ACT_RANGE, F16X3_WEIGHT_RANGE = 255.0, 63.0
@@ -665,8 +631,8 @@ def active_nsplit():
 
 
 def _split_weight(w, nsplit, frag=False):
-    """ (N, K) fp32 -> cached bf16 planes: (N, nsplit, K) or fragment order (rebuilt on change);
-    frag = "rows" with nsplit 22: row-major fp16 planes (N, 2, K) for the all-DMA planes GEMM """
+    """ (N, K) fp32 -> cached operand planes: bf16 (N, nsplit, K) or fragment order; nsplit 22: fp16 planes of 2^10 w in
+    fragment order (rebuilt when the weight changes) """
     key = (id(w), nsplit, frag)
     hit = _SPLIT_CACHE.get(key)
     # the weakref guards against id()/address reuse after the original weight was freed
@@ -678,12 +644,8 @@ def _split_weight(w, nsplit, frag=False):
     N, K = w.shape
     if nsplit == 22:
         out = torch.empty((N, 2, K), device=w.device, dtype=torch.float16)
-        if frag == "rows":
-            _check(lib().tocvp_split_weights_planes_f16(_ptr(w), _ptr(out), N, K, _stream()),
-                   "tocvp_split_weights_planes_f16")
-        else:
-            _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, K, _stream()),
-                   "tocvp_split_weights_frag_f16")
+        _check(lib().tocvp_split_weights_frag_f16(_ptr(w), _ptr(out), N, K, _stream()),
+               "tocvp_split_weights_frag_f16")
         _SPLIT_CACHE[key] = (weakref.ref(w), (w._version, w.data_ptr()), out)
         return out
     out = torch.empty((N, nsplit, K), device=w.device, dtype=torch.bfloat16)
@@ -864,26 +826,14 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, rowvec=None, rv_di
                                               int(bool(out_split)), N, mb, N, K, int(act), _stream()),
                 "tocvp_gemm_f16chunk_f32"))
     elif (frag_ok and pre_split and nsplit == 22 and _GEMM_MID and rowvec is None and N % 256 == 0 and K % 128 == 0 and
-            M <= _GEMM_MID_MAX_ROWS and ((M + 63) // 64) * (N // 256) >= _GEMM_MID_MIN_TILES and M * 4 * K < 2 ** 32 and
+            ((M + 63) // 64) * (N // 256) >= _GEMM_MID_MIN_TILES and M * 4 * K < 2 ** 32 and
             act in (ACT_NONE, ACT_RELU, ACT_GELU)):
-        # 64 x 256 tiles, A chunks by LDS-DMA, weights streamed, split-K over idle CUs (gemm_f16c.hip, mid-size form)
+        # 64 x 256 tiles, A chunks by LDS-DMA, weights streamed (gemm_f16c.hip, mid-size form)
         ws = _split_weight(w, 22, frag=True)
-        st = _stream()
-        wk_ptr, wk_bytes = (None, 0)
-        if _GEMM_MID_SPLITK:
-            _, wk_ptr, wk_bytes = _mid_workspace(w.device, st)
         _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
             lib().tocvp_gemm_f16mid_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out), int(bool(out_split)), N, M, N,
-                                        K, int(act), wk_ptr, wk_bytes, st),
+                                        K, int(act), _stream()),
             "tocvp_gemm_f16mid_f32"))
-    elif (frag_ok and pre_split and nsplit == 22 and _GEMM_P2 and rowvec is None and N % 256 == 0 and
-            M >= _GEMM_P2_MIN_ROWS and M * 4 * K < 2 ** 32):
-        # both operands as fp16 planes through LDS-DMA (gemm_f16p.hip)
-        ws = _split_weight(w, 22, frag="rows")
-        _timed(lambda: f"gemm_split{nsplit}_{M}x{N}x{K}", 2.0 * M * N * K, lambda: _check(
-            lib().tocvp_gemm_f16planes_f32(_ptr(x2), _ptr(ws), _ptr(bias), _ptr(r2), N, _ptr(out),
-                                           int(bool(out_split)), N, M, N, K, int(act), _stream()),
-            "tocvp_gemm_f16planes_f32"))
     elif frag_ok and nsplit == 22 and not pre_split and _GEMM_KSPLIT and M <= _GEMM_KSPLIT_MAX_ROWS:
         # few output tiles (small batches): split-K over idle CUs through a per-stream workspace
         ws = _split_weight(w, nsplit, frag=True)
@@ -1327,7 +1277,7 @@ def conv5x5_dec_f16x3_tail(x, wf, bias, taps, relu=True, out=None, pm_in=False, 
     """
     n, H, W, Cin = x.shape
     assert x.is_contiguous() and Cin == 64
-    planes = bool(planes) and bool(pm_in) and not _CHECK_RANGE and not _CONV_PERSISTENT   # as the producing call decided
+    planes = bool(planes) and bool(pm_in) and not _CHECK_RANGE   # as the producing call decided
     if _CHECK_RANGE:
         _check_f16_range(absmax(x), "conv5x5_dec_f16x3 (folded tail) input")
     if out is None:
@@ -1500,10 +1450,6 @@ def split_conv_weights_dec_f16x3(w):
     return wf
 
 
-# persistent form of the decoder conv (one workgroup per CU walking its tiles, next halo staged behind the MFMAs):
-# bit-identical results, measured equal to the two-workgroups-per-CU form (3.90 vs 3.92 ms per 2040 slot images,
-# profiles/r02_conv_f16x3_pmc.md) -> off by default
-_CONV_PERSISTENT = os.environ.get("TOCVP_CONV_PERSISTENT", "0") != "0"
 
 
 def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False, planes=False):
@@ -1515,7 +1461,7 @@ def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=Fa
     bytes, bit-identical results.  Never with the range check on (the planes cannot be inspected as fp32).
     """
     # (producer and consumer of a buffer are called with the same flag and see the same two switches)
-    planes = bool(planes) and bool(pm_in or pm_out) and not _CHECK_RANGE and not _CONV_PERSISTENT
+    planes = bool(planes) and bool(pm_in or pm_out) and not _CHECK_RANGE
     if collapsed is not None:
         cpos, S = collapsed
         H, W, Cin = cpos.shape
@@ -1538,7 +1484,7 @@ def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=Fa
         _check(lib().tocvp_conv5x5_dec_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf), _ptr(bias), _ptr(out),
                                                  n, H, W, Cin, Cout, int(bool(relu)),
                                                  int(bool(pm_in)) | (int(bool(pm_out)) << 1) |
-                                                 (4 if _CONV_PERSISTENT else 0) | (8 if planes else 0), _stream()),
+                                                 (8 if planes else 0), _stream()),
                "tocvp_conv5x5_dec_f16x3_f32")
     if TIMER is not None:
         TIMER.wrap(f"conv5x5_{Cin}_{Cout}", n, run)

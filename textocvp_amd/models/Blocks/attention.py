@@ -61,11 +61,9 @@ _CHUNK_GEMM = os.environ.get("TOCVP_PREDICTOR_CHUNK_GEMM", "0") != "0"
 # text cross-attention collapsed over the caption (csrc/xattn.hip): one fused kernel per block instead of
 # LayerNorm + q GEMM + attention + output GEMM; TOCVP_XATTN_COLLAPSE=0 keeps the four-kernel path
 _XATTN_COLLAPSE = os.environ.get("TOCVP_XATTN_COLLAPSE", "1") != "0"
-# longest caption (tokens) the collapsed kernel takes by default.  The 64-slot form for 33-50 tokens (end of round 4:
-# xattn_collapsed_kernel<64>, no FLOP saving any more, one kernel instead of four, one workgroup per CU) is built and
-# tested and measures EQUAL to the four-kernel path at 128 sequences (277-287 vs 280-287 us per block at 40 / 50 tokens;
-# 491-500 vs 546 us at 256) -- opt-in: TOCVP_XATTN_MAX_LT=64
-_XATTN_MAX_LT = int(os.environ.get("TOCVP_XATTN_MAX_LT", "32"))
+# longest caption (tokens) the collapsed kernel takes: 32 (captions of 33-50 tokens keep the four-kernel path; a 64-slot form of
+# the collapsed kernel was built in round 4, measured equal to it and retired in round 5)
+_XATTN_MAX_LT = 32
 
 
 class TextKV:
