@@ -8,6 +8,8 @@ the CPU are summation order and libm (expf/erff/tanhf) -> 2e-5 relative to the o
 
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1156,6 +1158,8 @@ def _planes_of(x2):
     return torch.stack([hi, (X - hi.float()).to(torch.float16)], dim=1).contiguous()
 
 
+@pytest.mark.skipif(os.environ.get("TOCVP_PRECISION") == "fp32" or os.environ.get("TOCVP_ATTN_QK") == "fp32",
+                    reason="operand planes exist in the f16x3 arithmetic only")
 @pytest.mark.parametrize("B,H,Tq,Tk,lens", [(5, 8, 300, 300, False), (3, 8, 30, 300, False), (2, 8, 77, 77, True),
                                             (24, 12, 257, 257, True), (1, 8, 30, 30, False), (9, 6, 257, 257, False)])
 def test_mha_planes_equals_the_fp32_input_kernel(B, H, Tq, Tk, lens, monkeypatch):

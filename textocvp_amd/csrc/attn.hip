@@ -34,12 +34,29 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// Exponentials of the online softmax (round 5): ONE v_exp_f32 each, in the log2 domain -- p = 2^(fma(score, k2, -max k2))
-// with k2 = scale log2(e) on the raw accumulator scores (no per-score multiplication; the argument carries the one rounding
-// of the fma).  Rounds 3-4 used the library expf's operations (13, then 9 instructions per exponential: 40 % of the vector
-// instructions of a kernel bound by their issue, profiles/r04_mha.md, r05_mha.md); against a float64 softmax the two forms
-// are equally accurate (tests/test_kernels_gpu.py::test_mha*).  The plane-input kernel (attn_planes.hip) uses the same
-// expressions: the two kernels agree bit for bit.
+// Exponentials of the online softmax.
+//  * QK16 (the default arithmetic, round 5): ONE v_exp_f32 each, in the log2 domain -- p = 2^(fma(score, k2, -max k2)) with
+//    k2 = scale log2(e) on the raw accumulator scores (no per-score multiplication; the argument carries the one rounding of
+//    the fma).  Rounds 3-4 used the library expf's operations here too (13, then 9 instructions per exponential: 40 % of the
+//    vector instructions of a kernel bound by their issue, profiles/r04_mha.md, r05_mha.md); against a float64 softmax the
+//    two forms are equally accurate.  The plane-input kernel (attn_planes.hip) uses the same expressions: the two kernels
+//    agree bit for bit.
+//  * exact-fp32 products (TOCVP_ATTN_QK=fp32 / TOCVP_PRECISION=fp32, the range-free fallback): the library expf's operations
+//    for x <= 0 without its two range selects (same operations in the same order, so the same bits as expf): ph + t =
+//    x log2(e) in two floats, 2^(ph + t - e) by v_exp_f32, scaled by 2^e.  One v_max keeps a masked score's difference
+//    (-1e30) inside the float -> int conversion; the result is 0 either way.
+__device__ __forceinline__ float mha_exp_lib(float x) {
+#pragma clang fp contract(off)   // ph must be the ROUNDED product in ph - e, as in the library
+    x = __builtin_fmaxf(x, -150.f);
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
+    const float ph = x * c;
+    float t = __builtin_fmaf(x, c, -ph);
+    t = __builtin_fmaf(x, cc, t);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + t;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+
 // QK16: BOTH products run on the f16 matrix cores with split operands (hi + lo fp16 planes of 2^8 x, three
 // v_mfma_f32_32x32x16_f16 per 16-deep step, fp32-class; arithmetic of gemm_bf16.hip Elem<true>, |q|, |k|,
 // |v| < 255): per 32-key tile and 32 queries at dh = 64, 12 + 12 matrix instructions of 32 cycles instead of
@@ -239,14 +256,16 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
         // (maximum, fma(score, k2, -max k2), v_exp_f32); with one (T5's relative positions) they move to the log2 domain first.
         float bm = NEG_BIG, alpha, ps = 0.f;
         const bool mask_tile = kb * 32 + 32 > kv_len;   // wave-uniform: only the last tile holds keys past the end
-        if (p.bias) {
+        if (p.bias || !QK16) {
+            // scaled scores (+ bias): log2 domain + v_exp_f32 under QK16, natural domain + the library's operations otherwise
+            const float ksc = QK16 ? k2 : sc1, kb_ = QK16 ? LOG2E : 1.f;
             const int q = min(q0 + wave * 32 + l31, p.Tq - 1);
-            const float* brow = p.bias + ((size_t)head * p.Tq + q) * p.Tk;
+            const float* brow = p.bias ? p.bias + ((size_t)head * p.Tq + q) * p.Tk : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + acc_row(r, h);
-                float sv = s[r] * k2;
-                if (key < kv_len) sv += brow[key] * LOG2E;
+                float sv = s[r] * ksc;
+                if (brow && key < kv_len) sv += brow[key] * kb_;
                 s[r] = sv;
             }
             if (mask_tile) {
@@ -257,10 +276,10 @@ __global__ __launch_bounds__(64 * NW) void mha_f32_kernel(MhaArgs p) {
             for (int r = 0; r < 16; ++r) bm = fmaxf(bm, s[r]);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
             const float m_new = fmaxf(m_run, bm);
-            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            alpha = QK16 ? __builtin_amdgcn_exp2f(m_run - m_new) : mha_exp_lib(m_run - m_new);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                s[r] = QK16 ? __builtin_amdgcn_exp2f(s[r] - m_new) : mha_exp_lib(s[r] - m_new);
                 ps += s[r];
             }
             m_run = m_new;
