@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TOCVP_BENCH_BATCH", 256)),
                     help="sequences per GPU per step")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (the semantics of the "
+                         "reference's nn.DataParallel, base/baseEvaluator.py:142-145, which scatters ONE batch over its "
+                         "devices); default: weak scaling, --batch sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-32 / 8 / 1 lines, the per-kernel pass and the "
                                                            "config-4 / training legs")
@@ -81,6 +85,69 @@ def parse():
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def per_rank_batch(args, world):
+    """ sequences per rank and step: --batch itself (weak scaling) or its share of the global batch (--strong) """
+    if not args.strong:
+        return args.batch
+    if args.batch % world:
+        raise SystemExit(f"--strong: the global batch {args.batch} is not a multiple of {world} ranks")
+    return args.batch // world
+
+
+class ClockSampler:
+    """
+    Shader clock of the visible GPU while a timed region runs: a thread reads the amdgpu hwmon node ``freq1_input`` (sclk, Hz)
+    every 5 ms.  The chip lowers its clock under its power limit, by a different amount on every box: a kernel's duration in
+    CYCLES (avg_launch_ms x sclk) separates code changes from box-to-box clock spread (the driver saw 3.728 -> 3.739 ms on the
+    dominant kernel across rounds 3-4 while builder boxes showed 3.60-3.83 ms for one tree).  ``None`` when the node is not readable.
+    """
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.path, self.samples, self._stop, self._thread = None, [], False, None
+        nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        if pci_bus_id is not None:
+            want = f":{int(pci_bus_id):02x}:"
+            hit = [n for n in nodes if want in os.path.realpath(os.path.dirname(os.path.dirname(os.path.dirname(n))))]
+            nodes = hit or nodes
+        for n in nodes:
+            try:
+                int(open(n).read())
+                self.path = n
+                break
+            except (OSError, ValueError):
+                continue
+
+    def start(self):
+        if self.path is None:
+            return
+        import threading
+        self.samples, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                try:
+                    self.samples.append(int(open(self.path).read()) / 1e6)
+                except (OSError, ValueError):
+                    pass
+                time.sleep(0.005)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        """ -> {"mean", "min", "max", "samples"} in MHz, or None """
+        if self._thread is None:
+            return None
+        self._stop = True
+        self._thread.join()
+        self._thread = None
+        if not self.samples:
+            return None
+        v = self.samples
+        return {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "samples": len(v),
+                "source": self.path}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -163,7 +230,7 @@ def stub_main(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
-    B = args.batch
+    B = per_rank_batch(args, world)
 
     def step(_inp):
         time.sleep(0.002 * (1 + rank % 3))                          # ranks finish at different times
@@ -188,7 +255,8 @@ def stub_main(args):
         print(json.dumps({"metric": "predicted frames/sec (STUB: no model, launcher / rendezvous / gather rehearsal)",
                           "value": round(frames / elapsed, 2), "unit": "predicted frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-                          "higher_is_better": True, "scaling": "weak", "stub": True,
+                          "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "stub": True,
+                          "global_batch": B * world,
                           "gathered_rows": int(rows.shape[0]),
                           "row_owner": [int(v) for v in (rows[:, 0, 0] // 1000).tolist()]}), flush=True)
     if world > 1:
@@ -479,7 +547,7 @@ def main():
         return run_timed(lambda i: step(i, **kw), inp, warmup, steps, fence, gather_metrics, reduce_max,
                          before=start_timer, after=stop_timer)
 
-    B = args.batch
+    B = per_rank_batch(args, world)
     inp = make_inputs(B)
     if rank == 0:
         log(f"world={world} batch/gpu={B} warmup={args.warmup} steps={args.steps}")
@@ -487,7 +555,11 @@ def main():
     # region 2 (value_no_overlap + the dominant kernel's roofline): the same K steps, serial order, HIP events
     # around the decoder convolutions only -- a kernel's duration is its own when nothing shares the chip.
     elapsed, _, all_metrics = timed(inp, args.warmup, args.steps, timer_only=(), overlap_decode=True)
+    clock = ClockSampler(getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)) if rank == 0 else None
+    if clock is not None:
+        clock.start()
     elapsed_no, timer, _ = timed(inp, 0, args.steps, overlap_decode=False)
+    sclk = clock.stop() if clock is not None else None
 
     # Outside the timed region (rank 0): one pass with the decoder NOT overlapped with the rollout and EVERY
     # instrumented kernel bracketed by HIP events (thousands of event pairs would perturb the timed region).
@@ -592,7 +664,15 @@ def main():
                         "frac_executed_mfma": round(units * achieved / peak, 4),
                         "traffic": traffic, "traffic_from": traffic_from, "launches": conv["launches"],
                         "avg_launch_ms": round(avg_ms, 4), "gflop_per_launch": round(gflop_per_launch, 2),
+                        # shader clock sampled during this region (amdgpu hwmon freq1_input) and the launch in CYCLES:
+                        # the chip is power-limited on this kernel and boxes differ by several % in clock, not in cycles
+                        "sclk_mhz": sclk,
+                        "kcycles_per_launch": round(avg_ms * sclk["mean"], 1) if sclk else None,
                         "share_of_step_time": round(conv["total_ms"] / 1e3 / elapsed_no, 3),
+                        "ceiling": "3 matrix products per algorithmic product cap frac at 0.333; the bare "
+                                   "v_mfma_f32_32x32x16_f16 loop sustains 1704 TFLOP/s on this chip under its power limit "
+                                   "(scripts/probes/mfma_shape_rate.hip) = 568 algorithmic = frac 0.227: this kernel runs at "
+                                   f"{100.0 * achieved / 568.0:.0f} % of that; HBM traffic 1.10 x algorithmic",
                         "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the second timed region: the "
                                 "same K steps without the decode / rollout overlap, value_no_overlap; "
                                 "algorithmic 0.839 GFLOP per slot image and layer, + 0.019 in the last layer, whose epilogue "
@@ -676,7 +756,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "value_no_overlap": round(frames / elapsed_no, 2),
             "ms_per_step_no_overlap": round(1e3 * elapsed_no / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": arithmetic_string(savi, pred, kernels),
             "data": "synthetic",
             "config": {"workload": "configs[1]: SAVi 30-slot 64x64 + TextOCVP_CustomTF predictor, "

@@ -153,6 +153,13 @@ def test_bench_launcher_end_to_end_with_eight_stub_ranks():
     assert line["gathered_rows"] == 8 * 2 * 2                       # ranks x steps x sequences per step
     assert line["row_owner"] == [r for r in range(8) for _ in range(4)]     # rows in rank order
     assert line["value"] > 0 and line["ms_per_step"] >= 2.0         # the slowest rank (6 ms per step) sets the time
+    # --strong: --batch is the GLOBAL batch, split over the ranks (the reference's nn.DataParallel scatters one batch)
+    res = _run_launcher(stub, "--gpus", "4", "--batch", "8", "--steps", "1", "--warmup", "0", "--strong")
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")][0]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 4 and line["global_batch"] == 8 and line["gathered_rows"] == 8
+    res = _run_launcher(stub, "--gpus", "3", "--batch", "8", "--steps", "1", "--warmup", "0", "--strong")
+    assert res.returncode != 0 and "not a multiple" in res.stderr
     # a rank that fails AFTER the collectives: every other rank ends cleanly, the launcher returns the worst code
     res = _run_launcher(dict(stub, TOCVP_BENCH_STUB_FAIL_RANK="5"), "--gpus", "8", "--batch", "1", "--steps", "1",
                         "--warmup", "0")
