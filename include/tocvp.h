@@ -117,6 +117,7 @@ size_t tocvp_mlp_f16x3_fused_ws_bytes(void);
 int tocvp_mlp_f16x3_fused_f32(const void* x_planes, const void* w1_frag, const float* b1, const void* w2_frag,
                               const float* b2, const float* R, int ldr, float* Y, int ldy, int M, int E, int Hd,
                               void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * f16x3 GEMM with the activation chunk resident in LDS (round 4, csrc/gemm_f16c.hip): C = act(A W^T + bias) (+ R) for
  * wide products (N % 512 == 0 or N % 384 == 0, K % 128 == 0) -- nn.Linear 1024 -> 1024 of the reference's MLPPatchDecoder
