@@ -476,8 +476,12 @@ int tocvp_conv3x3_f32(const float* x, const float* wp, const float* scale, const
                       float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                       void* stream);
 /* same convolution with f16x3 split operands (fp32-class, |x| < 255, |w| < 63; Cin % 32 == 0): 3/16 of the
- * matrix cycles of the fp32 MFMA form */
-int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale, const float* shift,
+ * matrix cycles of the fp32 MFMA form.  Round 5: ``wfrag`` = the fp16 operand planes of 2^10 w in MFMA-fragment order,
+ * made ONCE per weight version by tocvp_split_weights_frag_f16(packed, wfrag, taps * Cout, Cin) on the packed
+ * (taps, Cout, Cin) weights of tocvp_pack_conv_weights_f32 -- the kernel reads its weight fragments straight from L2 (rounds
+ * 2-4 took the fp32 packed weights and split a tap's slice per workgroup behind a barrier per tap).  The same holds for
+ * tocvp_conv3x3_up2_f16x3_f32 (packed: (4 phases x 4 taps, Cout, Cin)) and tocvp_conv5x5_f16x3_f32 ((25, Cout, Cin)). */
+int tocvp_conv3x3_f16x3_f32(const float* x, const void* wfrag, const float* scale, const float* shift,
                       float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                       void* stream);
 /* "Upsample(scale_factor=2) -> Conv2d(k3, p1)" of the image head (models/EncodersDecoders/decoders.py:325-365, the
@@ -489,12 +493,12 @@ int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale,
  *   reads source pixel (y + i + a - 1, x + j + b - 1) and holds the sum of w[:, :, dy, dx] over dy in rows(a, i),
  *   dx in rows(b, j), rows(0, 0) = {0}, rows(0, 1) = {1, 2}, rows(1, 0) = {0, 1}, rows(1, 1) = {2};
  *   y (nimg, 2 SH, 2 SW, Cout).  Cin % 32 == 0, Cout % 32 == 0, SH % 8 == 0. */
-int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, const float* scale, const float* shift,
+int tocvp_conv3x3_up2_f16x3_f32(const float* x, const void* wphase_frag, const float* scale, const float* shift,
                                 float* y, int nimg, int SH, int SW, int Cin, int Cout, int relu, void* stream);
 /* generic 5x5 convolution (pad 2, + bias, optional ReLU; Cin % 32 == 0, Cout % 32 == 0, H % 8 == 0) with
- * the same f16x3 split operands: SAVi encoder convs 32 -> 32 (encoders.py:99-159).  wp: (25, Cout, Cin)
- * from tocvp_pack_conv_weights_f32. */
-int tocvp_conv5x5_f16x3_f32(const float* x, const float* wp, const float* bias, float* y, int nimg,
+ * the same f16x3 split operands: SAVi encoder convs 32 -> 32 (encoders.py:99-159).  wfrag: fragment-order planes of the
+ * (25, Cout, Cin) weights of tocvp_pack_conv_weights_f32 (see tocvp_conv3x3_f16x3_f32). */
+int tocvp_conv5x5_f16x3_f32(const float* x, const void* wfrag, const float* bias, float* y, int nimg,
                             int H, int W, int Cin, int Cout, int relu, void* stream);
 int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B, int K, int N,
                              int F, int ld, void* stream);

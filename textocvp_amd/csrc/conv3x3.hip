@@ -193,11 +193,10 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
     const int oy0 = PH ? pa - 1 : -(KS / 2), ox0 = PH ? pb - 1 : -(KS / 2);     // first tap relative to the output pixel
     constexpr int COUTB = NB * 32;
     constexpr int F4 = CH / 4;
-    constexpr int WREG = (COUTB * F4) / 256;
     constexpr int NIT = (IH * IW * F4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[IH * IW * ROWB + 2 * COUTB * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IH * IW * ROWB];
     unsigned char* in_s = lds;
-    unsigned char* w_s = lds + IH * IW * ROWB;
+    typedef const __attribute__((address_space(1))) h16x8* gv8;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -219,24 +218,14 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 wreg[WREG];
-    auto wload = [&](int tap, int ch) {
-#pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int idx = t + 256 * i;
-            const int co = idx / F4, c = (idx % F4) * 4;
-            wreg[i] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)((PH ? (int)blockIdx.z * NTAP : 0) + tap) * p.Cout + co0 + co) * p.Cin +
-                                                      ch * CH + c);
-        }
-    };
-    auto wstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int idx = t + 256 * i;
-            const int co = idx / F4, c = (idx % F4) * 4;
-            split4_f16(wreg[i], TOCVP_F16X3_WEIGHT_SCALE, w_s + buf * COUTB * ROWB + co * ROWB + c * 2);
-        }
-    };
+    // weights: fp16 planes of 2^10 w in MFMA-FRAGMENT order, made once per weight version by tocvp_split_weights_frag_f16 on the
+    // packed (taps x Cout, Cin) matrix: Wf[(tap Cout + co) / 32][Cin / 16][plane][lane] 16 bytes each -- a B fragment is ONE
+    // coalesced 1 KiB load from L1 / L2 straight into the operand registers (round 5; rounds 2-4 split each tap's fp32 slice
+    // per workgroup into LDS behind a barrier per tap: 24 MFMAs between barriers, 0.08 of the f16 peak)
+    const int KC = p.Cin / 16;
+    const unsigned char* wf_base = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)lane * 16;
+    const size_t rb0 = (size_t)co0 / 32;                               // row block of this workgroup's first output channel
+    const size_t rb_tap = (size_t)p.Cout / 32;                         // row blocks per tap
 
     const int nch = p.Cin / CH;
     for (int ch = 0; ch < nch; ++ch) {
@@ -250,7 +239,6 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
             tv[it] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)img * SH + iy) * SW + ix) * p.Cin +
                                                      ch * CH + c);
         }
-        wload(0, ch);
         __syncthreads();   // previous chunk fully consumed
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -265,28 +253,29 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
                 split4_f16(v, TOCVP_F16X3_ACT_SCALE, in_s + pix * ROWB + c * 2);
             }
         }
-        wstore(0);
         __syncthreads();
 
+        // the taps of a chunk, fully unrolled (LDS offsets are immediates, no barrier inside): (ch, tap, ks) order as before
+        const unsigned char* wch = wf_base + ((size_t)(PH ? (int)blockIdx.z * NTAP : 0) * rb_tap + rb0) * KC * 2048 +
+                                   (size_t)ch * (CH / 16) * 2048;
+#pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
-            const int buf = tap & 1;
-            if (tap + 1 < NTAP) wload(tap + 1, ch);
-            __builtin_amdgcn_sched_barrier(0);
             const int dy = tap / KS, dx = tap % KS;
             const unsigned char* a_base = in_s + ((WROWS * wave + apy + dy) * IW + apx + dx) * ROWB + h * 16;
-            const unsigned char* b_base = w_s + buf * COUTB * ROWB + l31 * ROWB + h * 16;
+            const unsigned char* wtap = wch + (size_t)tap * rb_tap * KC * 2048;
 #pragma unroll
             for (int ks = 0; ks < CH / 16; ++ks) {
                 h16x8 ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const unsigned char* wp_ = wtap + ((size_t)n * KC + ks) * 2048;
+                    bh[n] = *(gv8)(wp_);
+                    bl[n] = *(gv8)(wp_ + 1024);
+                }
+#pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     ah[m] = *reinterpret_cast<const h16x8*>(a_base + m * MSTEP * IW * ROWB + ks * 32);
                     al[m] = *reinterpret_cast<const h16x8*>(a_base + m * MSTEP * IW * ROWB + ks * 32 + CH * 2);
-                }
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    bh[n] = *reinterpret_cast<const h16x8*>(b_base + n * 32 * ROWB + ks * 32);
-                    bl[n] = *reinterpret_cast<const h16x8*>(b_base + n * 32 * ROWB + ks * 32 + CH * 2);
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -297,8 +286,6 @@ __global__ __launch_bounds__(256, 2) void convk_f16x3_kernel(Conv3Args p) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
                     }
             }
-            if (tap + 1 < NTAP) wstore(buf ^ 1);
-            __syncthreads();
         }
     }
 
@@ -401,6 +388,8 @@ extern "C" int tocvp_conv3x3_f32(const float* x, const float* wp, const float* s
     return tocvp_launch_status();
 }
 
+// ``wp`` of the three f16x3 entries below: fp16 planes of 2^10 w in MFMA-fragment order (tocvp_split_weights_frag_f16 on the packed
+// (taps x Cout, Cin) matrix), passed through the float pointer of Conv3Args
 static int launch_convk_f16x3(const float* x, const float* wp, const float* scale, const float* shift,
                               float* y, int nimg, int H, int W, int Cin, int Cout, int relu, int upsample2,
                               int ksize, void* stream) {
@@ -430,13 +419,13 @@ static int launch_convk_f16x3(const float* x, const float* wp, const float* scal
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const float* wp, const float* scale,
+extern "C" int tocvp_conv3x3_f16x3_f32(const float* x, const void* wp, const float* scale,
                                        const float* shift, float* y, int nimg, int H, int W, int Cin,
                                        int Cout, int relu, int upsample2, void* stream) {
-    return launch_convk_f16x3(x, wp, scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2, 3, stream);
+    return launch_convk_f16x3(x, static_cast<const float*>(wp), scale, shift, y, nimg, H, W, Cin, Cout, relu, upsample2, 3, stream);
 }
 
-extern "C" int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, const float* scale, const float* shift,
+extern "C" int tocvp_conv3x3_up2_f16x3_f32(const float* x, const void* wphase, const float* scale, const float* shift,
                                            float* y, int nimg, int SH, int SW, int Cin, int Cout, int relu, void* stream) {
     TOCVP_CHECK_ARG(x && wphase && shift && y);
     TOCVP_CHECK_ARG(nimg >= 0 && SH > 0 && SW > 0 && (SH % TH) == 0);
@@ -445,7 +434,7 @@ extern "C" int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, 
     TOCVP_CHECK_ARG(nimg * tiles < 0x7fffffffu && Cout / 32 <= 65535);
     if (!tocvp_aligned16(x) || !tocvp_aligned16(wphase)) return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
-    Conv3Args a{x, wphase, scale, shift, y, nimg, SH, SW, Cin, Cout, relu, 0};
+    Conv3Args a{x, static_cast<const float*>(wphase), scale, shift, y, nimg, SH, SW, Cin, Cout, relu, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (SW <= 16 && (SH % 16) == 0) {                              // narrow source images: 16 x 16 tiles
         const unsigned nt = (unsigned)(nimg * (size_t)(SH / 16));
@@ -458,10 +447,10 @@ extern "C" int tocvp_conv3x3_up2_f16x3_f32(const float* x, const float* wphase, 
     return tocvp_launch_status();
 }
 
-extern "C" int tocvp_conv5x5_f16x3_f32(const float* x, const float* wp, const float* bias, float* y,
+extern "C" int tocvp_conv5x5_f16x3_f32(const float* x, const void* wp, const float* bias, float* y,
                                        int nimg, int H, int W, int Cin, int Cout, int relu,
                                        void* stream) {
-    return launch_convk_f16x3(x, wp, nullptr, bias, y, nimg, H, W, Cin, Cout, relu, 0, 5, stream);
+    return launch_convk_f16x3(x, static_cast<const float*>(wp), nullptr, bias, y, nimg, H, W, Cin, Cout, relu, 0, 5, stream);
 }
 
 extern "C" int tocvp_slot_composite_f32(const float* decoded, float* recons, float* masks, int B,

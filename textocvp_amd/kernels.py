@@ -1137,6 +1137,32 @@ def pos_embed(proj_weight, proj_bias, H, W):
     return out
 
 
+_CONV_FRAG = {}
+
+
+def conv_frag_weights(wp):
+    """
+    Packed conv weights (taps..., Cout, Cin) fp32 -> the fp16 operand planes of 2^10 w in MFMA-fragment order that the f16x3
+    convolutions of conv3x3.hip read straight from L2 (tocvp_split_weights_frag_f16 on the (taps x Cout, Cin) matrix); cached
+    per packed tensor, rebuilt when it changes.
+    """
+    key = id(wp)
+    hit = _CONV_FRAG.get(key)
+    if hit is not None and hit[0]() is wp and hit[1] == (wp._version, wp.data_ptr()):
+        return hit[2]
+    if len(_CONV_FRAG) > 1024:
+        for k_ in [k_ for k_, v in _CONV_FRAG.items() if v[0]() is None]:
+            del _CONV_FRAG[k_]
+    _dev_f32(wp, "conv weights")
+    assert wp.is_contiguous()
+    Cin = wp.shape[-1]
+    rows = wp.numel() // Cin
+    out = torch.empty((rows, 2, Cin), device=wp.device, dtype=torch.float16)
+    _check(lib().tocvp_split_weights_frag_f16(_ptr(wp), _ptr(out), rows, Cin, _stream()), "tocvp_split_weights_frag_f16")
+    _CONV_FRAG[key] = (weakref.ref(wp), (wp._version, wp.data_ptr()), out)
+    return out
+
+
 def pack_conv_weights(w):
     """ (Cout, Cin, k, k) -> (k*k, Cout, Cin) """
     Cout, Cin, k, _ = w.shape
@@ -1175,7 +1201,7 @@ def conv5x5(x, wp, bias, relu=True, out=None, precision="fp32"):
         _check_f16_weight_range(wp, "conv5x5 (f16x3)")
     def run():
         if split:
-            _check(lib().tocvp_conv5x5_f16x3_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), n, H, W, Cin,
+            _check(lib().tocvp_conv5x5_f16x3_f32(_ptr(x), _ptr(conv_frag_weights(wp)), _ptr(bias), _ptr(out), n, H, W, Cin,
                                                  Cout, int(bool(relu)), _stream()),
                    "tocvp_conv5x5_f16x3_f32")
             return
@@ -1523,7 +1549,8 @@ def conv3x3(x, wp, scale, shift, relu=True, upsample2=False, precision="fp32"):
         _check_f16_range(absmax(x), "conv3x3 (f16x3) input")
         _check_f16_weight_range(wp, "conv3x3 (f16x3)")
     fn = lib().tocvp_conv3x3_f16x3_f32 if precision == "f16x3" else lib().tocvp_conv3x3_f32
-    _check(fn(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
+    wk = conv_frag_weights(wp) if precision == "f16x3" else wp        # f16x3: fragment-order fp16 planes of the packed weights
+    _check(fn(_ptr(x), _ptr(wk), _ptr(scale), _ptr(shift), _ptr(y), n, H, W, Cin, Cout, int(bool(relu)),
               int(bool(upsample2)), _stream()), "tocvp_conv3x3_" + precision)
     return y
 
@@ -1559,7 +1586,7 @@ def conv3x3_up2(x, wphase, scale, shift, relu=True):
         _check_f16_range(absmax(x), "conv3x3_up2 (f16x3) input")
         _check_f16_weight_range(wphase, "conv3x3_up2 (f16x3)")
     _timed(lambda: f"conv3x3_up2_{n}x{SH}x{SW}x{Cin}x{Cout}", 2.0 * n * SH * SW * 16 * Cin * Cout, lambda: _check(
-        lib().tocvp_conv3x3_up2_f16x3_f32(_ptr(x), _ptr(wphase), _ptr(scale), _ptr(shift), _ptr(y), n, SH, SW, Cin, Cout,
+        lib().tocvp_conv3x3_up2_f16x3_f32(_ptr(x), _ptr(conv_frag_weights(wphase)), _ptr(scale), _ptr(shift), _ptr(y), n, SH, SW, Cin, Cout,
                                           int(bool(relu)), _stream()), "tocvp_conv3x3_up2_f16x3_f32"))
     return y
 
