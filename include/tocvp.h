@@ -563,6 +563,13 @@ int tocvp_gemm_tn_f32(const float* G, int ldg, const float* X, int ldx, float* c
  * tocvp_gemm_tn_f32 on the same partial buffers. */
 int tocvp_gemm_tn_bf16x3_f32(const float* G, int ldg, const float* X, int ldx, float* c_part, float* bias_part,
                              int M, int N, int K, int splits, int accumulate, void* stream);
+/* Round 5: the same product over SEVERAL row segments in ONE launch -- dW = sum_t G_t^T X_t of a weight that back-propagation
+ * through time uses once per rollout step (04_train_predictor.py:57-108 unrolls the rollout un-detached).  G[s] (rows[s] x N),
+ * X[s] (rows[s] x K), s < nseg <= 20, rows[s] % 32 == 0; G / X / rows are HOST arrays whose entries travel as kernel arguments
+ * (nothing to keep alive or to re-upload under a captured HIP graph).  Partial buffers, splits and accumulate as above, over
+ * the concatenated rows. */
+int tocvp_gemm_tn_bf16x3_multi_f32(const float* const* G, const float* const* X, const int* rows, int nseg, int ldg, int ldx,
+                                   float* c_part, float* bias_part, int N, int K, int splits, int accumulate, void* stream);
 /* Backward of multi-head softmax attention, fused (scores / probabilities never reach HBM), exact fp32 MFMA:
  * q, o, d_o, dq (B, Tq, E); k, v, dk, dv (B, Tk, E); E = H * 64; o = the forward output; stats (B, H, Tq, 2) is
  * scratch (log-sum-exp and <dO, O> per query row); key_len (B) int32 or NULL masks keys >= key_len[b] (their

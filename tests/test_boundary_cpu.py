@@ -5,6 +5,7 @@ captured from the reference), factories, error behaviour, C-ABI symbol table.  N
 
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -337,3 +338,10 @@ def test_cached_module_parameters_follow_every_way_of_replacing_them():
     finally:
         torch.__future__.set_overwrite_module_params_on_conversion(prev)
     assert blk2.layernorm_query.weight is not w0 and get_ln(blk2)[0] is blk2.layernorm_query.weight
+
+
+def test_every_knob_is_documented():
+    """ KNOBS.md lists every TOCVP_* environment variable the sources read, and nothing else """
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "list_knobs.py"), "--check"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr

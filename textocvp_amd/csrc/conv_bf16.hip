@@ -365,16 +365,8 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
                static_cast<const unsigned char*>(wfrag)};
     const dim3 grid((unsigned)((size_t)nimg * (H / TH) * (W / TW)));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // variants: "8x64" (8 waves, one pass, 1 workgroup/CU), "4x64", "4x32" / "8x32" (two channel
-    // passes, 80.6 KB LDS, 2 workgroups/CU).  Default chosen by measurement.
-    static const int variant = []() {
-        const char* e = getenv("TOCVP_CONV_VARIANT");
-        if (!e) return 432;
-        if (!strcmp(e, "8x64")) return 864;
-        if (!strcmp(e, "4x64")) return 464;
-        if (!strcmp(e, "8x32")) return 832;
-        return 432;
-    }();
+    // 4 waves, two 32-channel passes, 2 workgroups/CU (the "8x64" / "4x64" / "8x32" forms of round 1 lost their A/B: gone)
+    constexpr int variant = 432;
 #define TOCVP_LAUNCH_CONV(NW_, CCH_)                                                              \
     do {                                                                                          \
         if (in_mode == 0)                                                                         \
@@ -390,12 +382,7 @@ extern "C" int tocvp_conv5x5_bf16x3_f32(const float* x, const float* aux, int in
         return tocvp_launch_status();
     }
     TOCVP_CHECK_ARG(wsplit != nullptr);
-    switch (variant) {
-        case 864: TOCVP_LAUNCH_CONV(8, 64); break;
-        case 464: TOCVP_LAUNCH_CONV(4, 64); break;
-        case 832: TOCVP_LAUNCH_CONV(8, 32); break;
-        default: TOCVP_LAUNCH_CONV(4, 32); break;
-    }
+    TOCVP_LAUNCH_CONV(4, 32);
 #undef TOCVP_LAUNCH_CONV
     return tocvp_launch_status();
 }

@@ -841,13 +841,7 @@ int launch_wfrag(const GemmArgs& p, hipStream_t s) {
 
 // split-K plan of the 64 x 64 kernel: slices double while the grid stays within ~2 workgroups per CU, every slice
 // keeps >= 4 k-tiles (an even count: the loop takes two per iteration) and the records fit the workspace
-static int ksplit_wgs() {
-    static const int v = []() {
-        const char* e = getenv("TOCVP_GEMM_KSPLIT_WGS");
-        return e ? atoi(e) : 256;
-    }();
-    return v;
-}
+static int ksplit_wgs() { return 256; }                               // (tuned on one MI355X: 512 loses, scripts/ksplit_bench.py)
 static int pick_ksplit(const GemmArgs& p, int bk) {
     const int tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64), nk = p.K / bk, least = bk == 32 ? 4 : 2;
     int S = 1;
@@ -860,23 +854,13 @@ static int pick_ksplit(const GemmArgs& p, int bk) {
 // else 32; TOCVP_GEMM_SMALL_BK=32 pins the shallow form.  Measured (scripts/ksplit_bench.py, graph replay, us):
 // 300x512x2048 split-K 15.1 / 12.7 / 13.8 at BK 32 / 64 / 128, 2400x512x2048 41.4 / 36.4 / 37.7, K = 512 shapes equal at
 // 32 and 64 and 10-15 % slower at 128 (216 VGPRs, 66 KB LDS) -- the 128-deep form is not built.
-static int pick_small_bk(int K) {
-    static const int pinned = []() {
-        const char* e = getenv("TOCVP_GEMM_SMALL_BK");
-        return e ? atoi(e) : 0;
-    }();
-    return (pinned != 32 && K % 128 == 0) ? 64 : 32;
-}
+static int pick_small_bk(int K) { return K % 128 == 0 ? 64 : 32; }
 
 template <int BK>
 int launch_small_f16(const GemmArgs& p, hipStream_t s) {
     GemmArgs q = p;
     q.ksplit = p.ws_part ? pick_ksplit(p, BK) : 1;
-    static const int fence = []() {
-        const char* e = getenv("TOCVP_GEMM_KSPLIT_FENCE");
-        return e ? atoi(e) : 0;
-    }();
-    q.sk_fence = fence;
+    q.sk_fence = 0;                                                    // (diagnostic release fence of round 3: off)
     const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64;
     hipLaunchKernelGGL((gemm_bf16_wfrag_kernel<2, 64, 64, 32, 32, 4, 1, false, true, true, BK>),
                        dim3(ntm * ntn, q.ksplit), dim3(256), 0, s, q);
@@ -884,21 +868,11 @@ int launch_small_f16(const GemmArgs& p, hipStream_t s) {
 }
 
 // 128 x 128 tiles only when there are enough of them: below this count the 64 x 64 kernel fills the CUs better
-static long small_below() {
-    static const long v = []() {
-        const char* e = getenv("TOCVP_GEMM_SMALL_BELOW");
-        return e ? atol(e) : 192L;
-    }();
-    return v;
-}
+static long small_below() { return 192L; }
 
 int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    static const bool planes_kernel = []() {
-        const char* e = getenv("TOCVP_GEMM_PLANES");
-        return !e || atoi(e) != 0;
-    }();
-    if (planes_kernel && p.a_split && !p.rowvec && (p.N % 128) == 0 && (p.K % 64) == 0 && big_tiles >= 512 &&
+    if (p.a_split && !p.rowvec && (p.N % 128) == 0 && (p.K % 64) == 0 && big_tiles >= 512 &&
         (size_t)p.M * 2 * p.K * 2 < 0xffffffffull) {
         const int ntm = (p.M + 255) / 256, ntn = p.N / 128;
         hipLaunchKernelGGL(gemm_f16_planes_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
@@ -910,12 +884,7 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
         }
         return launch_wfrag<2, 64, 64, 32, 32, 4, 1, true>(p, s);
     }
-    static const int variant = []() {
-        const char* e = getenv("TOCVP_GEMM_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
-    if (variant == 1 && big_tiles >= 1024) return launch_wfrag<2, 256, 128, 64, 64, 8, 2, true>(p, s);
-    if (variant == 2) return launch_wfrag<2, 128, 128, 64, 32, 8, 2, true>(p, s);
+    // (256 x 128 / 8-wave and 128 x 128 / 8-wave forms were instantiated in rounds 1-4 behind TOCVP_GEMM_VARIANT and never won: gone)
     // (64-deep k-tiles in THIS kernel need 2 x 64 fragment registers: 256 VGPRs + 50 spilled, not built)
     // Also measured at the end of round 3 on 38400 x 2048 x 512 / 38400 x 512 x 2048 (scripts/probes/gemm_ablate.hip,
     // two rounds) and dropped: the four waves side by side along N (128 x 32 per wave: half the weight-fragment bytes on
@@ -926,32 +895,16 @@ int dispatch_wfrag_f16(const GemmArgs& p, hipStream_t s) {
 
 template <int NS>
 int dispatch_wfrag(const GemmArgs& p, hipStream_t s) {
-    static const int variant = []() {
-        const char* e = getenv("TOCVP_GEMM_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (big_tiles < small_below()) return launch_wfrag<NS, 64, 64, 32, 32, 4, 1>(p, s);
-    if (variant == 1 && big_tiles >= 1024) return launch_wfrag<NS, 256, 128, 64, 64, 8, 2>(p, s);
-    if (variant == 2) return launch_wfrag<NS, 128, 128, 64, 32, 8, 2>(p, s);
     return launch_wfrag<NS, 128, 128, 64, 64, 4, 2>(p, s);
 }
 
 template <int NS>
 int dispatch(const GemmArgs& p, hipStream_t s) {
-    static const int variant = []() {
-        const char* e = getenv("TOCVP_GEMM_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (big_tiles < 192) return launch<NS, 64, 64, 32, 32, 32, 4, 1>(p, s);
-    switch (variant) {
-        case 1: return launch<NS, 128, 128, 64, 32, 32, 8, 2>(p, s);   // 8 waves, BK 32
-        case 2: return launch<NS, 128, 128, 64, 64, 16, 4, 2>(p, s);   // 4 waves, BK 16, 2 WG/CU
-        case 3: return launch<NS, 128, 128, 64, 32, 16, 8, 4>(p, s);   // 8 waves, BK 16, 2 WG/CU
-        case 4: return launch<NS, 128, 128, 32, 64, 32, 8, 2>(p, s);   // 8 waves (32x64), BK 32
-        default: return launch<NS, 128, 128, 64, 64, 32, 4, 1>(p, s);
-    }
+    return launch<NS, 128, 128, 64, 64, 32, 4, 1>(p, s);
 }
 
 }  // namespace

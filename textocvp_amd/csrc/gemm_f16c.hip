@@ -595,10 +595,8 @@ extern "C" int tocvp_gc_read_stamps(unsigned long long* host, int n) {
 
 static int gc_cus() {
     static const int v = []() {
-        const char* e = getenv("TOCVP_GEMM_CHUNK_CUS");
         int dev = 0, n = 0;
-        if (e) n = atoi(e);
-        else if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             n = 256;
         return n >= 8 ? n / 8 * 8 : 8;
     }();

@@ -29,6 +29,16 @@ struct TnArgs {
     int ldg, ldx, M, N, K, chunk, accumulate;
 };
 
+// Several (G, X) row segments reduced by ONE launch (round 5): back-propagation through time uses every weight once per
+// rollout step, dW = sum_t G_t^T X_t is one product over the concatenated rows.  The pointers travel as kernel arguments (no
+// device-side table: a captured HIP graph holds them by value); rend[s] = rows of segments 0 .. s.
+constexpr int TN_MAXSEG = 20;
+struct TnSegs {
+    const float* G[TN_MAXSEG]; const float* X[TN_MAXSEG];
+    int rend[TN_MAXSEG];
+    int nseg;
+};
+
 #ifndef TOCVP_TN_STAGES
 #define TOCVP_TN_STAGES 3
 #endif
@@ -166,8 +176,8 @@ __device__ __forceinline__ tn_bf16x8 tn_tr_frag(const unsigned char* addr) {
 //         stage and wave 32 transposed reads + 16 plane stores + 32 elements to split for 24 MFMAs at MI = 2; 48 + 24
 //         + 48 for 48 MFMAs at MI = 4); ONE LDS stage (56 KB, two workgroups per CU) filled from registers behind a
 //         second barrier.  Measured slower in the training step (see the launch function): off by default.
-template <int MI>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
+template <int MI, bool MULTI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p, TnSegs sg) {
     constexpr int GN = 64 * MI;                                   // columns of the G (n) tile
     constexpr int RSG = GN * 2 + 64, RSX = 320;                   // row pitches: 64 bytes past a multiple of 256
     constexpr int GPLANE = TB_ROWS * RSG, XPLANE = TB_ROWS * RSX;
@@ -190,14 +200,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(TnArgs p) {
     const bool want_bias = p.bias != nullptr && blockIdx.x == 0;        // workgroup-uniform
     f32x4 gq[GPT], xq[4];
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    int cs = 0;                                                   // MULTI: segment of the tile being loaded (tiles never straddle)
     auto gload = [&](int it) {
-        const size_t row = (size_t)(r_lo + it * TB_ROWS);
+        size_t row = (size_t)(r_lo + it * TB_ROWS);
+        const float* G = p.G;
+        const float* X = p.X;
+        if (MULTI) {
+            const int R = r_lo + it * TB_ROWS;
+            while (cs + 1 < sg.nseg && R >= sg.rend[cs]) ++cs;     // workgroup-uniform, monotonic in ``it``
+            G = sg.G[cs];
+            X = sg.X[cs];
+            row = (size_t)(R - (cs ? sg.rend[cs - 1] : 0));
+        }
 #pragma unroll
         for (int i = 0; i < GPT; ++i)
-            gq[i] = *reinterpret_cast<const f32x4*>(p.G + (row + gr + GRS * i) * p.ldg + n0 + gc);
+            gq[i] = *reinterpret_cast<const f32x4*>(G + (row + gr + GRS * i) * p.ldg + n0 + gc);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            xq[i] = *reinterpret_cast<const f32x4*>(p.X + (row + xr + 8 * i) * p.ldx + k0 + xc);
+            xq[i] = *reinterpret_cast<const f32x4*>(X + (row + xr + 8 * i) * p.ldx + k0 + xc);
     };
     auto split_store = [&](unsigned char* dst, int plane, const f32x4 v) {
         tn_bf16x4 hi, lo;
@@ -340,19 +360,40 @@ extern "C" int tocvp_gemm_tn_bf16x3_f32(const float* G, int ldg, const float* X,
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TB_ROWS - 1) / TB_ROWS * TB_ROWS;
     TnArgs a{G, X, c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
-    // 256-row tiles (MI = 4) when they still give this many workgroups.  OFF by default: at the configs[1] shapes the
-    // training step measures 511.8 ms without them, 520.3 ms with them from 256 workgroups up and 529.5 ms from 128 up --
-    // the single LDS stage's second barrier costs more than the shared fragments save.  TOCVP_TN_WIDE_MIN_WGS=256 tries it.
-    static const long wide_min = []() {
-        const char* e = getenv("TOCVP_TN_WIDE_MIN_WGS");
-        return e ? atol(e) : (1L << 40);
-    }();
-    if (N % 256 == 0 && (long)(K / TN_T) * (N / 256) * splits >= wide_min) {
-        const dim3 grid(K / TN_T, N / 256, splits);
-        hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    } else {
-        const dim3 grid(K / TN_T, N / TN_T, splits);
-        hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // (256-row tiles -- gemm_tn_bf16x3_kernel<4> -- were built in round 3 and measured slower in the step, 520.3 vs 511.8 ms: gone)
+    const dim3 grid(K / TN_T, N / TN_T, splits);
+    hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<2, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, TnSegs{});
+    return tocvp_launch_status();
+}
+
+// dW (+ db) over SEVERAL row segments in one launch: G[s] (rows[s] x N, row stride ldg), X[s] (rows[s] x K, row stride ldx),
+// s < nseg <= 20, every rows[s] a multiple of 32.  ``G`` / ``X`` / ``rows`` are HOST arrays: their entries are copied into
+// the kernel's arguments.  Same partial buffers, split and accumulate semantics as tocvp_gemm_tn_bf16x3_f32 on the
+// concatenated rows; the sum over rows is associated per split of the CONCATENATED row range.
+extern "C" int tocvp_gemm_tn_bf16x3_multi_f32(const float* const* G, const float* const* X, const int* rows, int nseg, int ldg,
+                                              int ldx, float* c_part, float* bias_part, int N, int K, int splits,
+                                              int accumulate, void* stream) {
+    TOCVP_CHECK_ARG(G && X && rows && c_part && nseg >= 1 && nseg <= TN_MAXSEG);
+    TOCVP_CHECK_ARG(N > 0 && N % TN_T == 0 && K > 0 && K % TN_T == 0);
+    TOCVP_CHECK_ARG(ldg >= N && ldx >= K && ldg % 4 == 0 && ldx % 4 == 0);
+    TOCVP_CHECK_ARG(splits >= 1 && splits <= 65535);
+    TnSegs sg{};
+    long total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        TOCVP_CHECK_ARG(G[i] && X[i] && rows[i] > 0 && rows[i] % TB_ROWS == 0);
+        TOCVP_CHECK_ARG(tocvp_aligned16(G[i]) && tocvp_aligned16(X[i]));
+        total += rows[i];
+        TOCVP_CHECK_ARG(total < 0x7fffffffL);
+        sg.G[i] = G[i];
+        sg.X[i] = X[i];
+        sg.rend[i] = (int)total;
     }
+    sg.nseg = nseg;
+    const int M = (int)total;
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TB_ROWS - 1) / TB_ROWS * TB_ROWS;
+    TnArgs a{G[0], X[0], c_part, bias_part, ldg, ldx, M, N, K, chunk, accumulate ? 1 : 0};
+    const dim3 grid(K / TN_T, N / TN_T, splits);
+    hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<2, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, sg);
     return tocvp_launch_status();
 }

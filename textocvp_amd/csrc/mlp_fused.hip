@@ -553,8 +553,6 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_fused_kernel(MlpArgs p) {
 // then 44 tiles x 5 slices instead of 44 whole tiles on 44 CUs)
 static int mlp_cus() {
     static const int v = []() {
-        const char* e = getenv("TOCVP_MLP_CUS");
-        if (e) return atoi(e);
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;

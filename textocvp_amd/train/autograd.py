@@ -164,6 +164,35 @@ def _sum_splits(part):
     return res.reshape(n)
 
 
+# Weight gradients of ONE weight over all rollout steps in ONE launch (round 5): back-propagation through time uses every linear
+# once per step (04_train_predictor.py:57-108: predictions are fed back un-detached), and dW = sum_t g_t^T x_t is one product
+# over the concatenated rows -- tocvp_gemm_tn_bf16x3_multi_f32 takes up to 20 (g_t, x_t) segments as kernel arguments.  The
+# backward closures only PARK their (g, x) pair (both stay alive until the launch); a weight is flushed when 20 pairs wait
+# and when the tape finishes.  1583 launches of ~45 us per step became ~100 of long reductions.  TOCVP_TRAIN_WGRAD_DEFER=0:
+# one launch per use.
+_WGRAD_DEFER = os.environ.get("TOCVP_TRAIN_WGRAD_DEFER", "1") != "0"
+_WGRAD_MAXSEG = 20
+
+
+def _flush_weight_grad(ent):
+    pend = ent.pop("pending", None)
+    if not pend:
+        return
+    import ctypes
+    n = len(pend)
+    N, Kd = pend[0][0].shape[1], pend[0][1].shape[1]
+    G = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in pend])
+    X = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in pend])
+    rows = (ctypes.c_int * n)(*[g.shape[0] for g, _ in pend])
+    total = sum(g.shape[0] for g, _ in pend)
+    K._timed("gemm_tn", 2.0 * total * N * Kd, lambda: K._check(
+        _L().tocvp_gemm_tn_bf16x3_multi_f32(ctypes.cast(G, ctypes.c_void_p), ctypes.cast(X, ctypes.c_void_p),
+                                            ctypes.cast(rows, ctypes.c_void_p), n, N, Kd, _p(ent["part"]), _p(ent["bias"]), N, Kd,
+                                            ent["splits"], 1 if ent["written"] else 0, _s()),
+        "tocvp_gemm_tn_bf16x3_multi_f32"))
+    ent["written"] = True
+
+
 def _weight_grad_tn(tape, W, b, g, x2):
     """
     dW += g^T x2 (and db += column sums of g) on tocvp_gemm_tn_f32.  The split-K partial sums of one weight
@@ -179,22 +208,32 @@ def _weight_grad_tn(tape, W, b, g, x2):
         tiles = (N // 128) * (Kd // 128)
         splits = max(1, min(16, -(-_TN_TARGET_WGS // tiles), M // 64))
         ent = tape.cache[("tn", id(W))] = {
-            "W": W, "b": b if want_b else None, "splits": splits,
+            "W": W, "b": b if want_b else None, "splits": splits, "written": False,
             "part": torch.empty((splits, N * Kd), device=g.device, dtype=torch.float32),
             "bias": torch.empty((splits, N), device=g.device, dtype=torch.float32) if want_b else None}
-    # later (accumulating) uses with few rows touch only as many slices as they can keep busy
-    active = ent["splits"] if first else max(1, min(ent["splits"], M // 128))
+    if _WGRAD_DEFER and _WGRAD_PRECISION == "bf16x3" and M % 32 == 0 and g.is_contiguous() and x2.is_contiguous():
+        ent.setdefault("pending", []).append((g, x2))
+        if len(ent["pending"]) >= _WGRAD_MAXSEG:
+            _flush_weight_grad(ent)
+            return False
+        return True                                       # g and x2 are parked: nobody may write into them any more
+    # the first write covers every slice; later (accumulating) uses with few rows touch only as many slices as they can keep busy
+    fresh = not ent["written"]
+    active = ent["splits"] if fresh else max(1, min(ent["splits"], M // 128))
     if _WGRAD_PRECISION == "bf16x3" and M % 32 == 0:
         K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
             _L().tocvp_gemm_tn_bf16x3_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
-                                          active, 0 if first else 1, _s()), "tocvp_gemm_tn_bf16x3_f32"))
+                                          active, 0 if fresh else 1, _s()), "tocvp_gemm_tn_bf16x3_f32"))
     else:
         K._timed("gemm_tn", 2.0 * M * N * Kd, lambda: K._check(
             _L().tocvp_gemm_tn_f32(_p(g), N, _p(x2), Kd, _p(ent["part"]), _p(ent["bias"]), M, N, Kd,
-                                   active, 0 if first else 1, _s()), "tocvp_gemm_tn_f32"))
+                                   active, 0 if fresh else 1, _s()), "tocvp_gemm_tn_f32"))
+    ent["written"] = True
+    return False
 
 
 def _finish_weight_grad(ent):
+    _flush_weight_grad(ent)
     W, b = ent["W"], ent["b"]
     dW = _sum_splits(ent["part"]).reshape(W.data.shape)
     if W.grad is None:
@@ -255,8 +294,9 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
         # it wants transposed are copied (data movement).  Everything else takes the generic fp32 kernel.
         fast = M >= 256 and M % 64 == 0 and N % 64 == 0 and Kd % 64 == 0
         tn = _TN and W.requires_grad and M >= 256 and M % 16 == 0 and N % 128 == 0 and Kd % 128 == 0
-        if tn:                                            # dW and db in one transpose-free launch
-            _weight_grad_tn(tape, W, b, g, x2)
+        parked = False
+        if tn:                                            # dW and db in one transpose-free launch (or parked for it)
+            parked = _weight_grad_tn(tape, W, b, g, x2)
         elif W.requires_grad:                             # dW (N, K) = g^T (N, M) x (M, K)
             splits = min(16, M // 512)
             if fast and M >= 8192 and (N // 64) * (Kd // 64) < 128 and M % splits == 0:
@@ -306,7 +346,9 @@ def linear(tape, x, W, b=None, act=K.ACT_NONE, precision="f16x3", residual=None)
                 bmm(g, W.data, dx, M, Kd, N, N, Kd, Kd)
                 accumulate(x, dx)
         if residual is not None:                          # last: the residual branch may take over out.grad
-            accumulate(residual, out.grad)
+            # (a parked gradient stays this weight's operand until its launch: the residual branch, whose later consumers add
+            # into what it owns IN PLACE, gets a copy)
+            accumulate(residual, out.grad.clone() if parked and g.data_ptr() == out.grad.data_ptr() else out.grad)
     tape.record(backward)
     return out
 
