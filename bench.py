@@ -731,7 +731,9 @@ def main():
                 tf = g["units"] / g["total_ms"] / 1e9
                 au = 3 if kernels._ATTN_QK16 else 1
                 apeak = F16_MFMA_PEAK_TFLOPS if kernels._ATTN_QK16 else FP32_MFMA_PEAK_TFLOPS
-                rooflines.append({"bound": "mfma", "kernel": f"mha_f32_kernel, predictor attention {name[4:]} "
+                aname = "mha_planes_kernel (q / k / v as fp16 operand planes from the projection's epilogue)" \
+                    if kernels._ATTN_QK16 and kernels._MHA_PLANES else "mha_f32_kernel"
+                rooflines.append({"bound": "mfma", "kernel": f"{aname}, predictor attention {name[4:]} "
                                   f"(B x heads x Tq x Tk x dh), QK^T + PV", "achieved": round(tf, 2),
                                   "peak": apeak, "unit": "TFLOP/s", "frac": round(tf / apeak, 4),
                                   "matrix_units_per_product": au, "frac_executed_mfma": round(au * tf / apeak, 4),

@@ -291,8 +291,12 @@ def mlp_patch_decoder(sd, slots, img_size, patch_size=14, num_layers_cnn=4):
 # ------------------------------------------------------------------------------------------------
 # ViT backbone of ExtendedDINOSAUR  (models/EncodersDecoders/timm_encoders.py:18-96)
 #
-# PARITY UNPINNED: the arithmetic lives in the third-party package `timm` (un-pinned in the reference's
-# environment.yml:24 and absent from this image), and the reference holds no test vector for it.  This
+# The arithmetic lives in the third-party package `timm` (un-pinned in the reference's environment.yml:24
+# and absent from this image), and the reference holds no test vector for it.  PINNED since round 5 by
+# `tests/golden/dinov2_vit.npz` / `e2e_c4.npz`: the reference's own ViTEncoder / ExtendedDINOSAUR code run in
+# the build container with `transformers.Dinov2Model` -- an independent implementation of the same network,
+# its state dict renamed key by key to timm's (`make_golden.py: HFDinov2AsTimm, hf_to_timm_key`) -- behind
+# timm's attribute names (tests/test_oracle_golden.py::test_vit_oracle_vs_dinov2, ::test_e2e_c4_*).  This
 # function restates timm's PUBLISHED VisionTransformer algorithm (timm/models/vision_transformer.py,
 # 0.9.x: PatchEmbed = Conv2d(k = s = patch) + flatten; _pos_embed = cat(cls_token, x) + pos_embed;
 # Block = x + ls1(attn(norm1(x))), x + ls2(mlp(norm2(x))) with LayerScale gamma, fused qkv Linear with

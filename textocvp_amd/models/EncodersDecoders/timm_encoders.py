@@ -2,8 +2,9 @@
 DINOv2 ViT backbone of ExtendedDINOSAUR on the MI355X kernels.
 Reference: models/EncodersDecoders/timm_encoders.py (ViTEncoder :18-96, factories :215-267) wrapping
 timm's VisionTransformer.  timm is third-party and absent from this image: the arithmetic below follows
-timm's published VisionTransformer (PARITY UNPINNED; the test suite holds a CPU restatement of the same
-published algorithm),
+timm's published VisionTransformer.  Pinned since round 5: `tests/golden/dinov2_vit.npz` holds the output
+of the reference's own ViTEncoder code with `transformers.Dinov2Model` (an independent implementation of
+the DINOv2 network, weights renamed key by key to timm's) behind timm's attribute names, at 224 and 336;
 the parameter names are timm's, so a reference checkpoint's ``encoder.vit_backbone.*`` entries load strictly.
 
     ViTEncoder.forward (timm_encoders.py:59-70):

@@ -3,8 +3,9 @@ ExtendedDINOSAUR video decomposition model on the MI355X kernels.
 Reference: models/ExtendedDINOSAUR.py (forward_decomp :139-208, decode :211-214).
 
 The frozen DINOv2 ViT backbone (models/EncodersDecoders/timm_encoders.py, third-party timm arithmetic:
-parity unpinned, restated from timm's published algorithm) runs on the same GEMM / attention / LayerNorm
-kernels as the predictor.  ``forward_decomp`` batches everything that does not depend on the slots over
+restated from timm's published algorithm; pinned since round 5 by `tests/golden/dinov2_vit.npz`: the
+reference's wrapper around `transformers.Dinov2Model`, an independent implementation of the same
+network) runs on the same GEMM / attention / LayerNorm kernels as the predictor.  ``forward_decomp`` batches everything that does not depend on the slots over
 all frames (backbone, feature projection, k/v projection); only the slot recurrence is sequential.
 The extension kwarg ``encoded_img_feats`` (B, T, N, mlp_encoder_dim) bypasses the backbone (features
 computed elsewhere, e.g. cached across predictor experiments).
