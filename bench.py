@@ -56,6 +56,9 @@ PATH_GFLOP_PER_FRAME = 149.5             # reference algorithm, 
 CONV_MODES = {
     "f16x3": ("conv5x5_dec_f16x3_kernel (decoder 5x5 conv 64->64, split-fp16 operands: 3 f16 MFMA products "
               "per algorithmic product, fp32-class)", 3, F16_MFMA_PEAK_TFLOPS),
+    "f16x3-wino": ("conv5x5_wino_f16x3_kernel (decoder 5x5 conv 64->64 as vertical Winograd F(4, 5) x five horizontal taps: "
+                   "40 split-fp16 products per 4 output pixels instead of 100, 3 f16 MFMA products each, fp32-class)",
+                   1.2, F16_MFMA_PEAK_TFLOPS),
     "bf16x3": ("conv5x5_bf16x3_kernel (decoder 5x5 conv 64->64, split-bf16 operands, 3 bf16 MFMA products per "
                "algorithmic product)", 3, F16_MFMA_PEAK_TFLOPS),
     "f16f8": ("conv5x5_f16f8_kernel (decoder 5x5 conv 64->64, hybrid split: f16 main product + two e4m3 cross "
@@ -635,6 +638,8 @@ def main():
     if rank == 0:
         frames = world * B * NUM_PREDS * args.steps
         cp = savi.decoder.conv_precision
+        if cp == "f16x3" and getattr(savi.decoder, "conv_wino", False):
+            cp = "f16x3-wino"
         kernel_name, units, peak = CONV_MODES.get(cp, CONV_MODES["fp32"])
         rooflines = []
         roofline = None
@@ -669,10 +674,11 @@ def main():
                         "sclk_mhz": sclk,
                         "kcycles_per_launch": round(avg_ms * sclk["mean"], 1) if sclk else None,
                         "share_of_step_time": round(conv["total_ms"] / 1e3 / elapsed_no, 3),
-                        "ceiling": "3 matrix products per algorithmic product cap frac at 0.333; the bare "
-                                   "v_mfma_f32_32x32x16_f16 loop sustains 1704 TFLOP/s on this chip under its power limit "
-                                   "(scripts/probes/mfma_shape_rate.hip) = 568 algorithmic = frac 0.227: this kernel runs at "
-                                   f"{100.0 * achieved / 568.0:.0f} % of that; HBM traffic 1.10 x algorithmic",
+                        "ceiling": (f"{units:g} executed matrix products per algorithmic product cap frac at {1.0 / units:.3f}; "
+                                    "the bare v_mfma_f32_32x32x16_f16 loop sustains 1704 TFLOP/s on this chip under its power "
+                                    f"limit (scripts/probes/mfma_shape_rate.hip) = {1704.0 / units:.0f} algorithmic = frac "
+                                    f"{1704.0 / units / peak:.3f}: this kernel runs at {100.0 * achieved * units / 1704.0:.0f} % "
+                                    "of that"),
                         "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the second timed region: the "
                                 "same K steps without the decode / rollout overlap, value_no_overlap; "
                                 "algorithmic 0.839 GFLOP per slot image and layer, + 0.019 in the last layer, whose epilogue "

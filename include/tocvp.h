@@ -369,6 +369,32 @@ int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, c
                                 int relu, int layout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same decoder conv (nn.Conv2d(64, 64, 5, padding=2) + ReLU, models/EncodersDecoders/decoders.py:96-110) as a
+ * vertical Winograd F(4, 5) with five direct horizontal taps (round 5, csrc/conv_wino.hip): 40 split-fp16 matrix
+ * products per four output pixels instead of 100, transforms in fp32.  Not bit-identical to the entry above (another
+ * summation); scripts/probes/winograd_numerics.py: same error class against fp64 (4.1e-7 vs 3.1e-7 of the activation
+ * maximum after three layers).
+ *   Weights: tocvp_split_conv_weights_wino_f16x3 is called twice -- scales == NULL: absmax_out[8] (device) receives
+ *   max |U_xi| of the eight transformed weight rows; then the HOST picks powers of two scales[xi] with
+ *   scales[xi] * max |U_xi| <= 2^14 and calls again with them (host array) to get wf
+ *   (tocvp_conv_weights_wino_f16x3_bytes() bytes, fragment order).
+ *   coef (host array of 32 floats): AT[a][xi] / (16 * scales[xi]), AT = the 4 x 8 output transform over the points
+ *   0, 1, -1, 2, -2, 1/2, -1/2, infinity (rows: p^a; column 7: (0, 0, 0, 1)).
+ *   in_mode: 0 fp32 x 16 pass-major (n, 4, H, W, 16) as written by out_mode 1; 1 collapsed first layer (x = cpos
+ *   (H, W, 64), aux = (nimg, 25, 64), as tocvp_conv5x5_f32); 2 fp32 NHWC.
+ *   out_mode: 0 fp32 NHWC; 1 fp32 x 16 pass-major; 2 fp16 operand planes of 2^8 y, pass-major (the planes input of
+ *   tocvp_conv5x5_dec_f16x3_f32 / _tail_f32); 3 (tail_taps != NULL, else NULL) y = (nimg, 36, H, W) tap products of the
+ *   folded decoder tail (tocvp_pack_tail_taps_f16x3, summed by tocvp_dec_tail_sum_f32).
+ * H % 8 == 0, W % 64 == 0.  Valid for |x| < 255 (operands saturate beyond); no limit on the weights.
+ * ------------------------------------------------------------------------------------------- */
+size_t tocvp_conv_weights_wino_f16x3_bytes(void);
+int tocvp_split_conv_weights_wino_f16x3(const float* w, void* wf, const float* scales, float* absmax_out, int Cout,
+                                        int Cin, void* stream);
+int tocvp_conv5x5_dec_wino_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf, const float* coef,
+                                     const float* bias, const void* tail_taps, float* y, int nimg, int H, int W,
+                                     int relu, int out_mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Decoder tail folded into the last hidden layer.  The tail Conv2d(64 -> 4, k = 3) (decoders.py:112-117) is linear,
  * so the last 5 x 5 layer's epilogue multiplies every pixel's 64 outputs (bias + ReLU applied, still on the chip,
  * no halo) with the 36 x 64 tap matrix (rows 4 t + o, t = 3 ky + kx) in the same split-fp16 arithmetic and writes

@@ -667,6 +667,94 @@ def test_conv5x5_dec_f16x3_collapsed_input_and_range():
         k.split_conv_weights_dec_f16x3(w_big.to(DEV))
 
 
+@pytest.mark.parametrize("n,HW", [(3, 64), (37, 64), (3, 128)])
+def test_conv5x5_dec_wino_is_fp32_class(n, HW):
+    """ the Winograd form of the decoder conv (vertical F(4, 5), split-fp16 products): same error class against fp64 as
+    the direct split-fp16 kernel; NHWC and x 16 pass-major layouts; borders, exact zeros, tiny and large activations """
+    k = _k()
+    x = rnd(f"wx{HW}", (n, HW, HW, 64))
+    x[0, :4, :4] = 0.0
+    x[0, 5, 5, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 1e-3, 40.0, -90.0, 200.0, 0.25])
+    x[1] = x[1] * 1e-3
+    w = rnd("ww", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("wb", (64,), "uniform", 0.1)
+    lin = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2).permute(0, 2, 3, 1)
+    ref = torch.relu(lin)
+    wp = k.split_conv_weights_wino_f16x3(w.to(DEV))
+    got = k.conv5x5_dec_wino(x.to(DEV), wp, b.to(DEV), relu=True)
+    direct = k.conv5x5_dec_f16x3(x.to(DEV), k.split_conv_weights_dec_f16x3(w.to(DEV)), b.to(DEV), relu=True)
+    err = (got.cpu().double() - ref).abs()
+    err_d = (direct.cpu().double() - ref).abs().max().item()
+    scale = ref[2:].abs().max().item()
+    print(f"Winograd decoder conv {HW}: max abs err {err.max().item():.3e} (direct f16x3 {err_d:.3e}) at scale {scale:.3g}; "
+          f"small image {err[1].max().item():.3e}")
+    assert err.max().item() < max(4.0 * err_d, 3e-6 * scale)      # outliers (200 next to O(1)) cost the transform ~3x
+    assert err[1].max().item() < 3e-6
+    got_lin = k.conv5x5_dec_wino(x.to(DEV), wp, b.to(DEV), relu=False)
+    assert (got_lin.cpu().double() - lin).abs().max().item() < max(4.0 * err_d, 3e-6 * lin.abs().max().item())
+    # x 16 pass-major out, then in: same values in the other layout / a second layer on top
+    y16 = k.conv5x5_dec_wino(x.to(DEV), wp, b.to(DEV), relu=True, out_mode=1)
+    assert torch.equal(y16.cpu().reshape(n, HW, HW, 64), _to_pass_major(got.cpu() * 16.0))
+    w2 = rnd("ww2", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    wp2 = k.split_conv_weights_wino_f16x3(w2.to(DEV))
+    z = k.conv5x5_dec_wino(y16, wp2, b.to(DEV), relu=True, in_mode=0)
+    z_ref = torch.relu(F.conv2d(got.cpu().double().permute(0, 3, 1, 2), w2.double(), b.double(), padding=2)).permute(0, 2, 3, 1)
+    assert (z.cpu().double() - z_ref).abs().max().item() < 3e-6 * z_ref.abs().max().item()
+    assert torch.equal(z, k.conv5x5_dec_wino(got, wp2, b.to(DEV), relu=True, in_mode=2))
+    # operand planes out == the planes the direct kernel writes for the same values
+    pl = k.conv5x5_dec_wino(x.to(DEV), wp, b.to(DEV), relu=True, out_mode=2)
+    plf = pl.view(torch.float16).view(n, 4, HW, HW, 2, 16).float().sum(4)
+    want = (got.cpu().view(n, HW, HW, 4, 16).permute(0, 3, 1, 2, 4) * 256.0).clamp(-65504.0, 65504.0)
+    assert (plf.cpu() - want).abs().max().item() <= 2.0 ** -10 * 256.0 * 255.0 * 2.0 ** -11
+
+
+def test_conv5x5_dec_wino_collapsed_tail_and_wide_weights():
+    """ first-layer (collapsed) mode, the folded decoder tail in the epilogue, and weights far outside the direct
+    kernel's |w| < 63 range (the per-row scales are picked from the weights) """
+    k = _k()
+    n, D, C0 = 6, 128, 64
+    slots = rnd("dslots", (n, D))
+    pw, pb = rnd("dpw", (D, 4, 1, 1)), rnd("dpb", (D,))
+    w0 = rnd("dw0", (C0, D, 5, 5), "uniform", (25 * D) ** -0.5)
+    b0 = rnd("db0", (C0,), "uniform", 0.1)
+    w1 = rnd("dw1", (64, C0, 5, 5), "uniform", (25 * C0) ** -0.5)
+    b1 = rnd("db1", (64,), "uniform", 0.1)
+    pos = O.soft_pos_embed(pw, pb, (64, 64))
+    x0 = (slots[:, None, None, :] + pos[None]).permute(0, 3, 1, 2)
+    a0 = torch.relu(F.conv2d(x0.double(), w0.double(), b0.double(), padding=2))
+    ref = torch.relu(F.conv2d(a0, w1.double(), b1.double(), padding=2)).permute(0, 2, 3, 1)
+    pos_d = k.pos_embed(pw.to(DEV), pb.to(DEV), 64, 64)
+    cpos = k.conv5x5(pos_d[None].contiguous(), k.pack_conv_weights(w0.to(DEV)), b0.to(DEV), relu=False)[0]
+    tapsum = k.dec_tapsum(w0.to(DEV))
+    S = k.linear(slots.to(DEV), tapsum.reshape(25 * C0, D)).reshape(n, 25, C0)
+    wp = k.split_conv_weights_wino_f16x3(w1.to(DEV))
+    got = k.conv5x5_dec_wino(None, wp, b1.to(DEV), relu=True, collapsed=(cpos.contiguous(), S.contiguous()))
+    err = (got.cpu().double() - ref).abs().max().item()
+    print(f"Winograd collapsed conv: max abs err {err:.3e} at scale {ref.abs().max().item():.3g}")
+    assert err < 3e-6 * ref.abs().max().item()
+    # folded tail: products of this layer's output with the tap matrix == the direct kernel's, to rounding
+    Fr, K = 2, 3
+    wt = rnd("fwt", (4, 64, 3, 3), "uniform", 0.1)
+    bt = rnd("fbt", (4,), "uniform", 0.3)
+    taps = k.pack_tail_taps_f16x3(wt.to(DEV))
+    P = k.conv5x5_dec_wino(got, wp, b1.to(DEV), relu=True, in_mode=2, out_mode=3, tail_taps=taps)
+    imgs, rec, masks = k.dec_tail_sum(P, bt.to(DEV), Fr, K)
+    y3 = torch.relu(F.conv2d(got.cpu().double().permute(0, 3, 1, 2), w1.double(), b1.double(), padding=2))
+    y = F.conv2d(y3, wt.double(), bt.double(), padding=1).reshape(Fr, K, 4, 64, 64)
+    ref_rec, ref_masks = y[:, :, :3], torch.softmax(y[:, :, 3:], dim=1)
+    ref_imgs = (ref_rec * ref_masks).sum(1)
+    for g_, r_, name in ((rec, ref_rec, "recons"), (masks, ref_masks, "masks"), (imgs, ref_imgs, "imgs")):
+        e = (g_.cpu().double() - r_.reshape(g_.shape)).abs().max().item()
+        print(f"Winograd folded tail {name}: err {e:.2e}")
+        assert e < 3e-6 * max(1.0, r_.abs().max().item())
+    # weights of any range
+    w_big = w1 * 3000.0
+    got_big = k.conv5x5_dec_wino(x0.permute(0, 2, 3, 1).contiguous().to(DEV)[:, :, :, :64].contiguous(),
+                                 k.split_conv_weights_wino_f16x3(w_big.to(DEV)), b1.to(DEV), relu=False)
+    ref_big = F.conv2d(x0[:, :64].double(), w_big.double(), b1.double(), padding=2).permute(0, 2, 3, 1)
+    assert (got_big.cpu().double() - ref_big).abs().max().item() < 3e-6 * ref_big.abs().max().item()
+
+
 @pytest.mark.parametrize("M", [333, 5003])
 def test_f16_operand_planes_from_producers(M):
     """ LayerNorm / attention / GEMM epilogues emitting fp16 operand planes (2^8 x, hi + lo) feed the

@@ -380,11 +380,13 @@ def test_loaded_weights_are_range_checked_once():
     assert savi2._range_unchecked
     savi2(mode="decode", slots=dslots)
     assert not savi2._range_unchecked and savi2.decoder.conv_precision == "f16x3"
-    # a weight beyond |w| < 63 is caught when the fp16 weight image is built
+    # a weight beyond the direct kernel's |w| < 63 is caught when its fp16 weight image is built; the Winograd form scales
+    # its weight rows from the weights at hand (no limit), and the range check sees what such a weight does to the activations
     sd2 = {k_: v.clone() for k_, v in savi2.state_dict().items()}
     sd2["decoder.decoder.2.block.0.weight"][0, 0, 0, 0] = 100.0
     savi2.load_state_dict(sd2)
-    with pytest.raises(K.TocvpRangeError, match="weight out of the fp16-plane range"):
+    with pytest.raises(K.TocvpRangeError, match="out of the fp16-plane range" if savi2.decoder.conv_wino
+                       else "weight out of the fp16-plane range"):
         savi2(mode="decode", slots=dslots)
 
 

@@ -7,6 +7,7 @@ library is missing or a call fails, this module raises.
 """
 
 import ctypes
+import math
 import os
 import struct
 import weakref
@@ -185,6 +186,13 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv_weights_wino_f16x3_bytes": (ctypes.c_size_t, []),
+    "tocvp_split_conv_weights_wino_f16x3": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "tocvp_conv5x5_dec_wino_f16x3_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p]),
     "tocvp_conv_weights_dec_f16x3_bytes": (ctypes.c_size_t, []),
     "tocvp_split_conv_weights_dec_f16x3": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -1479,6 +1487,81 @@ def split_conv_weights_dec_f16x3(w):
     return wf
 
 
+
+
+# output transform of the vertical Winograd F(4, 5) (csrc/conv_wino.hip): rows p^a over the points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+_WINO_AT = [[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0],
+            [0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 0.0],
+            [0.0, 1.0, 1.0, 4.0, 4.0, 0.25, 0.25, 0.0],
+            [0.0, 1.0, -1.0, 8.0, -8.0, 0.125, -0.125, 1.0]]
+
+
+def split_conv_weights_wino_f16x3(w):
+    """
+    (64, 64, 5, 5) fp32 -> (wf, coef): the fragment-order fp16 planes of the eight transformed weight rows of the
+    Winograd decoder conv, each scaled by the largest power of two that keeps it below 2^14 (chosen here from the
+    weights at hand: nothing saturates, whatever their range), and the 32 output-transform coefficients
+    AT[a][xi] / (16 * scale[xi]) as a ctypes float array (kernel arguments of conv5x5_dec_wino).
+    """
+    Cout, Cin = w.shape[:2]
+    w = w.contiguous()
+    amax = torch.empty(8, device=w.device, dtype=torch.float32)
+    _check(lib().tocvp_split_conv_weights_wino_f16x3(_ptr(w), None, None, _ptr(amax), Cout, Cin, _stream()),
+           "tocvp_split_conv_weights_wino_f16x3 (absmax)")
+    amax = [float(v) for v in amax.tolist()]
+    if not all(math.isfinite(v) for v in amax):
+        raise ValueError("decoder conv weights are not finite")
+    scales = [2.0 ** max(-40, min(40, math.floor(math.log2(16384.0 / max(v, 1e-30))))) for v in amax]
+    sc = (ctypes.c_float * 8)(*scales)
+    wf = torch.empty(lib().tocvp_conv_weights_wino_f16x3_bytes(), device=w.device, dtype=torch.uint8)
+    _check(lib().tocvp_split_conv_weights_wino_f16x3(_ptr(w), _ptr(wf), ctypes.cast(sc, ctypes.c_void_p), None, Cout, Cin,
+                                                     _stream()), "tocvp_split_conv_weights_wino_f16x3")
+    coef = (ctypes.c_float * 32)(*[_WINO_AT[a][q] / (16.0 * scales[q]) for a in range(4) for q in range(8)])
+    return wf, coef
+
+
+def conv5x5_dec_wino(x, wpack, bias, relu=True, out=None, collapsed=None, in_mode=2, out_mode=0, tail_taps=None):
+    """
+    64 -> 64 5x5 conv as vertical Winograd F(4, 5) with split-fp16 products (tocvp_conv5x5_dec_wino_f16x3_f32).
+    wpack = split_conv_weights_wino_f16x3(weight).  in_mode 0: x is (n, 4, H, W, 16) fp32 holding 16 * activation (what
+    out_mode 1 writes), 2: NHWC fp32; collapsed = (cpos, S): first layer.  out_mode 0 NHWC fp32, 1 the x 16 pass-major
+    buffer, 2 fp16 operand planes for conv5x5_dec_f16x3(_tail) (never with the range check on), 3 with tail_taps: the
+    (n, 36, H, W) tap products of the folded decoder tail.
+    """
+    wf, coef = wpack
+    if collapsed is not None:
+        cpos, S = collapsed
+        H, W, Cin = cpos.shape
+        n = S.shape[0]
+        assert cpos.is_contiguous() and S.is_contiguous() and S.shape[1:] == (25, Cin)
+        xin, aux, mode, dev = cpos, S, 1, cpos.device
+        if _CHECK_RANGE:
+            _check_f16_range(absmax(cpos) + absmax(S), "conv5x5_dec_wino layer-0 bound")
+    else:
+        assert x.is_contiguous() and in_mode in (0, 2)
+        if in_mode == 0:
+            n, _, H, W, _ = x.shape
+        else:
+            n, H, W, _ = x.shape
+        xin, aux, mode, dev = x, None, in_mode, x.device
+        if _CHECK_RANGE:
+            _check_f16_range(absmax(xin) * (1.0 / 16.0 if in_mode == 0 else 1.0), "conv5x5_dec_wino input")
+    assert not (out_mode == 2 and _CHECK_RANGE)
+    assert (out_mode == 3) == (tail_taps is not None)
+    if out is None:
+        shape = {0: (n, H, W, 64), 1: (n, 4, H, W, 16), 2: (n, 4, H, W, 16), 3: (n, 36, H, W)}[out_mode]
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+
+    def run():
+        _check(lib().tocvp_conv5x5_dec_wino_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf),
+                                                      ctypes.cast(coef, ctypes.c_void_p), _ptr(bias), _ptr(tail_taps),
+                                                      _ptr(out), n, H, W, int(bool(relu)), out_mode, _stream()),
+               "tocvp_conv5x5_dec_wino_f16x3_f32")
+    if TIMER is not None:
+        TIMER.wrap("conv5x5_64_64", n, run)
+    else:
+        run()
+    return out
 
 
 def conv5x5_dec_f16x3(x, wf, bias, relu=True, out=None, collapsed=None, pm_in=False, pm_out=False, planes=False):

@@ -87,6 +87,9 @@ class ConvDecoder(nn.Module):
         # the tail Conv2d(64 -> 4, k = 3) folded into the last hidden layer's epilogue (36 tap products per pixel leave
         # the chip instead of 64 channels; tocvp_dec_tail_sum_f32 adds the nine shifted planes)
         self.tail_fold = os.environ.get("TOCVP_DEC_TAIL_FOLD", "1") != "0"
+        # the 64 -> 64 layers as vertical Winograd F(4, 5) x five horizontal taps (csrc/conv_wino.hip): 2.5 x fewer
+        # matrix products in the same split-fp16 arithmetic, same error class (scripts/probes/winograd_numerics.py)
+        self.conv_wino = os.environ.get("TOCVP_CONV_WINO", "1") != "0"
 
     # -- derived weights -----------------------------------------------------------------------
     def _packed(self, i):
@@ -112,6 +115,11 @@ class ConvDecoder(nn.Module):
         conv = self.decoder[i].conv
         return self._derived.get(f"w16{i}", [conv.weight],
                                  lambda: K.split_conv_weights_dec_f16x3(conv.weight))
+
+    def _wino(self, i):
+        conv = self.decoder[i].conv
+        return self._derived.get(f"wino{i}", [conv.weight],
+                                 lambda: K.split_conv_weights_wino_f16x3(conv.weight))
 
     def _tail_taps(self):
         tail = self.decoder[len(self.hidden_dims)]
@@ -163,7 +171,7 @@ class ConvDecoder(nn.Module):
             f1 = min(F_, f0 + fpc)
             n = (f1 - f0) * Ks
             S = K.linear(slots[f0:f1].reshape(n, D), tapsum).reshape(n, 25, C0)
-            x, which, pm_prev, folded, check_last = None, 0, False, False, False
+            x, which, pm_prev, folded, check_last, x16_prev = None, 0, False, False, False, False
             for i in range(1, n_hidden):
                 conv = self.decoder[i].conv
                 co = conv.weight.shape[0]
@@ -182,6 +190,24 @@ class ConvDecoder(nn.Module):
                     # hidden activation leaves the range raises here and takes the decoder's fallback (bf16x3, no fold)
                     fold = False
                     check_last = True
+                if self.conv_wino and self.conv_precision == "f16x3" and c64 and W % 64 == 0 and H % 8 == 0:
+                    # Winograd layers hand 16 * activation over in the pass-major fp32 layout; the last one writes the
+                    # folded tail's tap products (or NHWC fp32 for the exact tail on the range-checked pass)
+                    nxt = self.decoder[i + 1].conv if i + 1 < n_hidden else None
+                    last = nxt is None or tuple(nxt.weight.shape[:2]) != (64, 64)     # no Winograd layer behind this one
+                    kw = dict(collapsed=(cpos, S)) if i == 1 else dict(in_mode=0 if x16_prev else 2)
+                    x16_prev = not last
+                    if fold:
+                        if prod is None or prod.shape[0] != n:
+                            prod = torch.empty((n, 36, H, W), device=dev, dtype=torch.float32)
+                        K.conv5x5_dec_wino(x, self._wino(i), conv.bias, relu=True, out=prod, out_mode=3,
+                                           tail_taps=self._tail_taps(), **kw)
+                        folded = True
+                        break
+                    x = K.conv5x5_dec_wino(x, self._wino(i), conv.bias, relu=True,
+                                           out=out if last else out.view(n, 4, H, W, 16), out_mode=0 if last else 1, **kw)
+                    which ^= 1
+                    continue
                 if fold:
                     # last hidden layer: the tail's tap products leave its epilogue, the tail only sums them
                     if prod is None or prod.shape[0] != n:

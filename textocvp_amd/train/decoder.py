@@ -48,6 +48,8 @@ class DecoderLoss:
 
     def _conv_fwd(self, i, x, collapsed=None):
         conv = self.dec.decoder[i].conv
+        if self.dec.conv_precision == "f16x3" and self.dec.conv_wino:
+            return K.conv5x5_dec_wino(x, self.dec._wino(i), conv.bias, relu=True, collapsed=collapsed, in_mode=2)
         if self.dec.conv_precision == "f16x3":
             return K.conv5x5_dec_f16x3(x, self.dec._split16(i), conv.bias, relu=True, collapsed=collapsed)
         if self.dec.conv_precision == "f16f8":
