@@ -23,13 +23,22 @@
 // 32-pixel halves and both 32-channel halves = 8 tiles = 128 registers -- the per-wave shape of conv_f16x3.hip, so a
 // weight fragment from L2 feeds four pixel blocks and an operand fragment from LDS two channel blocks.  Four passes of
 // 16 input channels: every thread loads a column of 8 input rows (4 channels), transforms it, splits the 8 results and
-// writes them into the LDS image [t][xi][x 68][16 Vh | 16 Vl | pad] (87 KB); then 5 steps (dx) of 24 MFMAs per wave.
-// After the last pass the eight M_xi meet through LDS (two rounds of 128 KB, one per t): wave w combines row a = w / 2,
-// pixel half w % 2 for all 64 channels with AT scaled by the inverse operand scales (kernel arguments), adds bias /
-// ReLU and stores (fp32 NHWC, fp32 x 16 pass-major for the next layer of this kernel, fp16 operand planes for
+// writes them into the LDS image [t][xi][x 68][Vh | Vl] (68 KB, XOR-swizzled 16-byte chunks, two images: the transform
+// of pass p + 1 runs on one wave of every SIMD while the other wave multiplies pass p); 5 steps (dx) of 24 MFMAs per
+// wave and pass.  After the last pass the eight M_xi meet through LDS (two rounds of 128 KB, one per t): wave w combines
+// a 4-row x 8-column block of both channel halves with AT scaled by the inverse operand scales (kernel arguments), adds
+// bias / ReLU and stores (fp32 NHWC, fp32 x 16 pass-major for the next layer of this kernel, fp16 operand planes for
 // conv_f16x3.hip, or -- last hidden layer -- the 36 tap products of the folded decoder tail).
+//
+// Built without packed-f32 vector instructions (flags line below): next to another wave's MFMAs a v_pk_fma_f32 costs ~30
+// issue cycles against 2 x 4 for the two v_fma_f32 it replaces (MI355X_MICROARCH: packed f32 VALU "an anti-lever beside
+// MFMAs"), and the transform of one pass runs beside the partner wave's multiply of the previous one.  (The host
+// half of the compilation does not know the feature and says so; harmless.)
+// TOCVP_HIPCC_FLAGS: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -41,13 +50,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 64, IW = TW + 4;
 constexpr int NXI = 8, NT_ROWS = 2;                 // transform rows, 4-row groups per tile
 constexpr int C = 64, CCH = 16, NPASS = 4, NDX = 5, NSTEP = NPASS * NDX;
-constexpr int ROWB = 80, OFF_LO = 32;
+constexpr int OFF_LO = 32;
 constexpr int FRAG = 1024, STEP_BYTES = 4 * FRAG;   // [plane(h, l)][nb(2)] fragments of one (xi, pass, dx)
 constexpr float VS = 16.f;                          // scale of the transformed operand (and of a "x 16" activation buffer)
 constexpr float F16MAX = 65504.f;
-constexpr int IMG_BYTES = NT_ROWS * NXI * IW * ROWB;            // 87040
+constexpr int IMG_BYTES = NT_ROWS * NXI * IW * 64;              // 69632: one pass, unpadded (swizzled chunks)
 constexpr int XCH_BYTES = NXI * 4 * 4 * 64 * 16;                // 131072: [xi][tile 4][quad 4][lane 64][4 floats]
-constexpr int LDS_BYTES = XCH_BYTES > IMG_BYTES ? XCH_BYTES : IMG_BYTES;
+constexpr int LDS_BYTES = XCH_BYTES > 2 * IMG_BYTES ? XCH_BYTES : 2 * IMG_BYTES;
 constexpr int NTHREADS = 512;
 
 struct WArgs {
@@ -57,6 +66,21 @@ struct WArgs {
     const unsigned char* tail_wf;   // TAILP: tap matrix of the folded decoder tail (conv_f16x3.hip: pack_tail_taps_kernel)
     float coef[4 * NXI];            // AT[a][xi] / (VS * s_xi)
 };
+
+// -DTOCVP_WINO_STAMP (scripts/probes/wino_stamp.hip): s_memtime at the phase boundaries of waves 0 and 4, summed per workgroup
+#ifdef TOCVP_WINO_STAMP
+__device__ unsigned long long tocvp_wino_stamps[16384 * 2 * 16];
+#define WINO_T(i)                                                     \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        stamp_acc[i] += now_ - stamp_last;                            \
+        stamp_last = now_;                                            \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+#else
+#define WINO_T(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ int border_class(int p, int n) {
     return p < 2 ? p : (p >= n - 2 ? 4 - (n - 1 - p) : 2);
@@ -73,7 +97,6 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
 template <int MODE, bool TAILP>
 __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* in_s = lds;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -96,158 +119,232 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
     const char* const xbase = reinterpret_cast<const char*>(MODE == 1 ? p.x : p.x + (size_t)img * p.H * p.W * C);
     const char* const abase = reinterpret_cast<const char*>(MODE == 1 ? p.aux + (size_t)img * 25 * C : p.x);
 
-    int a_off[4];
+    // LDS image of one pass: [t 2][xi 8][x 68] pixels of 64 B = four 16-byte chunks (Vh ch 0-7, Vh 8-15, Vl 0-7, Vl 8-15),
+    // chunk c of column x stored at position c ^ ((x >> 2) & 3): a ds_read_b128 of 16 lanes (consecutive columns, one
+    // chunk) then touches every bank once at any tap shift -- no padding, so TWO images fit (139 KB) and the transform of
+    // pass p + 1 runs while pass p multiplies.  Byte offset of this lane's operand (column l31 + dx, k-half h, plane Vh);
+    // plane Vl is at offset ^ 32.
+    int o_dx[NDX];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a_off[m] = (((m >> 1) * NXI + wave) * IW + (m & 1) * 32 + l31) * ROWB + h * 16;
+    for (int dx = 0; dx < NDX; ++dx) {
+        const int x = l31 + dx;
+        o_dx[dx] = (x << 6) | (((h ^ (x >> 2)) & 3) << 4);
+    }
 
-    // weights of this wave's transform row: [xi][pass][dx][plane][nb][lane] 16 B, three rolling register slots,
-    // a step's fragments are loaded three steps ahead of their use (across the passes' barriers)
-    const unsigned char* const wbase = p.wf + (size_t)wave * NSTEP * STEP_BYTES + lane * 16;
-    f16x8 w3[3][2][2];
-    auto load_w = [&](int slot, int step) {
+    // weights of this wave's transform row: [xi][pass][dx][plane][nb][lane] 16 B, two register slots: step s lives in slot
+    // s % 2 and is loaded while step s - 1 multiplies (24 MFMAs = 768 matrix cycles ahead of its use, across the passes'
+    // barriers).  The pass loop below runs two passes (10 steps) per iteration, so the slot of a step is a compile-time
+    // choice without copying registers.
+    const unsigned char* wptr = p.wf + (size_t)wave * NSTEP * STEP_BYTES + lane * 16;     // fragments of the next step to load
+    f16x8 w2[2][2][2];
+    auto load_w = [&](int slot) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-                w3[slot][pl][n] = *reinterpret_cast<const f16x8*>(wbase + (size_t)step * STEP_BYTES + (pl * 2 + n) * FRAG);
+                w2[slot][pl][n] = *reinterpret_cast<const f16x8*>(wptr + (pl * 2 + n) * FRAG);
+        wptr += STEP_BYTES;
     };
-    load_w(0, 0);
-    load_w(1, 1);
-    load_w(2, 2);
+    load_w(0);
 
-    for (int pass = 0; pass < NPASS; ++pass) {
-        if (pass > 0) __syncthreads();          // every wave is done reading the previous image
-        // ---- input columns -> V planes in LDS.  Thread (4-row group tq, column xi, channel quad cq): 8 rows x 4 channels.
-        {
-            int tt = t;
-            asm volatile("" : "+v"(tt));         // keeps the staging addresses per-pass temporaries
-            const int tq = tt >> 8, rem = tt & 255, cq = rem & 3;
-#pragma unroll 1
-            for (int rep = 0; rep < 2; ++rep) {
-                if (rep == 1 && rem >= 16) break;                   // the four halo columns 64..67: 16 threads per row group
-                const int xi = rep ? 64 + (rem >> 2) : (rem >> 2);
-                const int ix = tx0 + xi - 2;
-                const int ixc = min(max(ix, 0), p.W - 1);
-                const bool xin = ix >= 0 && ix < p.W;
-                const int c = pass * CCH + cq * 4;
-                f32x4 d[8];
-                f32x4 ts[MODE == 1 ? 8 : 1];
+    const bool wide = p.W != TW;
+#ifdef TOCVP_WINO_STAMP
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_readcyclecounter();
+    const unsigned long long stamp_first = stamp_last;
+#endif
+    // ---- input columns -> V planes.  Thread (4-row group tq, column xi, channel quad cq): 8 rows x 4 channels.
+    // The LOADS of a transform (t_load) are issued one matrix step ahead of its arithmetic (t_store): a tile's input is the
+    // previous launch's output, i.e. HBM latency, and a transform that waits for it is as long as a multiply phase.
+    // rep 0: the 64 columns of the tile (image columns 2..65); rep 1: the four halo columns 0, 1, 66, 67 by 16 threads per
+    // row group -- only when the tile has neighbours (W > 64, never prefetched): at W == 64 they are zero padding,
+    // written once below.
+    constexpr bool PREFETCH = MODE != 1;        // the collapsed layer reads two small L2-resident tables
+    auto t_load = [&](int pass, int rep, f32x4 (&d)[8], f32x4 (&ts)[MODE == 1 ? 8 : 1]) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));             // keeps the staging addresses temporaries
+        const int tq = tt >> 8, rem = tt & 255, cq = rem & 3;
+        const int xi = rep ? ((rem >> 2) < 2 ? (rem >> 2) : 64 + (rem >> 2)) : 2 + (rem >> 2);
+        const int ixc = min(max(tx0 + xi - 2, 0), p.W - 1);
+        const int pc = min(pass, NPASS - 1);     // a load past the last pass is harmless and unused
+        const int c = pc * CCH + cq * 4;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int iy = ty0 + 4 * tq - 2 + i;
-                    const int iyc = min(max(iy, 0), p.H - 1);
-                    unsigned off;
-                    if (MODE == 0) off = (unsigned)(((pass * p.H + iyc) * p.W + ixc) * CCH + cq * 4) * 4u;
-                    else off = (unsigned)((iyc * p.W + ixc) * C + c) * 4u;
-                    d[i] = *reinterpret_cast<const f32x4*>(xbase + off);
-                    if (MODE == 1) {
-                        const int cls = border_class(iyc, p.H) * 5 + border_class(ixc, p.W);
-                        ts[i] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(cls * C + c) * 4u);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int iy = ty0 + 4 * tq - 2 + i;
-                    const bool inside = xin && iy >= 0 && iy < p.H;
-                    if (MODE == 1) {
-                        d[i] += ts[i];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) d[i][u] = fmaxf(d[i][u], 0.f) * VS;
-                    } else if (MODE == 2) {
-                        d[i] *= VS;
-                    }
-                    if (!inside) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                // BT (points 0, 1, -1, 2, -2, 1/2, -1/2, inf), even / odd parts shared by the +- pairs
-                f32x4 v[8];
-                v[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
-                v[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
-                {
-                    const f32x4 e = (d[2] + d[6]) - 4.25f * d[4], o = (d[1] + d[5]) - 4.25f * d[3];
-                    v[1] = e + o;
-                    v[2] = e - o;
-                }
-                {
-                    const f32x4 e = (0.25f * d[2] + d[6]) - 1.25f * d[4], o = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
-                    v[3] = e + o;
-                    v[4] = e - o;
-                }
-                {
-                    const f32x4 e = (4.f * d[2] + d[6]) - 5.f * d[4], o = (2.f * d[1] + 0.5f * d[5]) - 2.5f * d[3];
-                    v[5] = e + o;
-                    v[6] = e - o;
-                }
-                unsigned char* dst = in_s + ((tq * NXI) * IW + xi) * ROWB + cq * 8;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    f16x4 hi, lo;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float X = clampf(v[q][u], F16MAX);
-                        hi[u] = (_Float16)X;
-                        lo[u] = (_Float16)(X - (float)hi[u]);
-                    }
-                    *reinterpret_cast<f16x4*>(dst + q * IW * ROWB) = hi;
-                    *reinterpret_cast<f16x4*>(dst + q * IW * ROWB + OFF_LO) = lo;
-                }
+        for (int i = 0; i < 8; ++i) {
+            const int iyc = min(max(ty0 + 4 * tq - 2 + i, 0), p.H - 1);
+            unsigned off;
+            if (MODE == 0) off = (unsigned)(((pc * p.H + iyc) * p.W + ixc) * CCH + cq * 4) * 4u;
+            else off = (unsigned)((iyc * p.W + ixc) * C + c) * 4u;
+            d[i] = *reinterpret_cast<const f32x4*>(xbase + off);
+            if (MODE == 1) {
+                const int cls = border_class(iyc, p.H) * 5 + border_class(ixc, p.W);
+                ts[i] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(cls * C + c) * 4u);
             }
         }
-        __syncthreads();
-
-        f16x8 fa[2][4][2];                                          // [set][tile m][plane]
-        auto read_rows = [&](int set, int dx) {
-            const unsigned char* a_base = in_s + dx * ROWB;
+    };
+    auto t_store = [&](int rep, f32x4 (&d)[8], f32x4 (&ts)[MODE == 1 ? 8 : 1], unsigned char* img_s) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int tq = tt >> 8, rem = tt & 255, cq = rem & 3;
+        const int xi = rep ? ((rem >> 2) < 2 ? (rem >> 2) : 64 + (rem >> 2)) : 2 + (rem >> 2);
+        const int ix = tx0 + xi - 2;
+        const bool xin = ix >= 0 && ix < p.W;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                fa[set][m][0] = *reinterpret_cast<const f16x8*>(a_base + a_off[m]);
-                fa[set][m][1] = *reinterpret_cast<const f16x8*>(a_base + a_off[m] + OFF_LO);
+        for (int i = 0; i < 8; ++i) {
+            const int iy = ty0 + 4 * tq - 2 + i;
+            const bool inside = xin && iy >= 0 && iy < p.H;
+            if (MODE == 1) {
+                d[i] += ts[i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[i][u] = fmaxf(d[i][u], 0.f) * VS;
+            } else if (MODE == 2) {
+                d[i] *= VS;
             }
+            if (!inside) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // BT (points 0, 1, -1, 2, -2, 1/2, -1/2, inf), even / odd parts shared by the +- pairs
+        f32x4 v[8];
+        v[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
+        v[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+        {
+            const f32x4 e = (d[2] + d[6]) - 4.25f * d[4], o = (d[1] + d[5]) - 4.25f * d[3];
+            v[1] = e + o;
+            v[2] = e - o;
+        }
+        {
+            const f32x4 e = (0.25f * d[2] + d[6]) - 1.25f * d[4], o = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
+            v[3] = e + o;
+            v[4] = e - o;
+        }
+        {
+            const f32x4 e = (4.f * d[2] + d[6]) - 5.f * d[4], o = (2.f * d[1] + 0.5f * d[5]) - 2.5f * d[3];
+            v[5] = e + o;
+            v[6] = e - o;
+        }
+        unsigned char* dst = img_s + (((tq * NXI) * IW + xi) << 6) + ((((cq >> 1) ^ (xi >> 2)) & 3) << 4) + (cq & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float X = clampf(v[q][u], F16MAX);
+                hi[u] = (_Float16)X;
+                lo[u] = (_Float16)(X - (float)hi[u]);
+            }
+            *reinterpret_cast<f16x4*>(dst + q * IW * 64) = hi;
+            *reinterpret_cast<f16x4*>((unsigned char*)((size_t)(dst + q * IW * 64) ^ 32)) = lo;
+        }
+    };
+    f32x4 dpre[8];                               // the prefetched columns of the next transform (PREFETCH)
+    f32x4 tsx[MODE == 1 ? 8 : 1];
+    // the arithmetic + LDS stores of the transform of `pass` (its loads too where they were not issued ahead)
+    auto transform = [&](int pass, unsigned char* img_s, bool loaded) {
+        if (!PREFETCH || !loaded) t_load(pass, 0, dpre, tsx);
+#ifdef TOCVP_WINO_STAMP
+        WINO_T(8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WINO_T(9);
+#endif
+        t_store(0, dpre, tsx, img_s);
+#ifdef TOCVP_WINO_STAMP
+        WINO_T(10);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WINO_T(11);
+#endif
+        if (wide && (t & 255) < 16) {
+            t_load(pass, 1, dpre, tsx);
+            t_store(1, dpre, tsx, img_s);
+        }
+    };
+
+    // ---- 5 steps (dx) of 24 MFMAs on the image of one pass; PAR = parity of the pass (slot of its first step, LDS image)
+    auto multiply = [&](auto par_tag, bool last_pass, int prefetch_pass) {
+        constexpr int PAR = decltype(par_tag)::value;
+        // LDS offset of this wave's rows in image PAR (an opaque copy per pass: the per-step address arithmetic stays
+        // two vector instructions instead of values kept, and spilled, across the passes)
+        int wofs = PAR * IMG_BYTES + wave * (IW * 64);
+        asm volatile("" : "+s"(wofs));
+        // operand fragments [tile m][plane]: ONE set -- the fragments of tile m for step dx + 1 are read into the same
+        // registers right behind tile m's six MFMAs of step dx, 18 MFMAs ahead of their use
+        f16x8 fa[4][2];
+        auto read_tile = [&](int m, int dx) {
+            const int toff = (m >> 1) * NXI * IW * 64 + (m & 1) * 32 * 64;
+            fa[m][0] = *reinterpret_cast<const f16x8*>(lds + (o_dx[dx] + wofs) + toff);
+            fa[m][1] = *reinterpret_cast<const f16x8*>(lds + ((o_dx[dx] ^ 32) + wofs) + toff);
         };
-        read_rows(0, 0);
+        // the multiplying wave outranks its partner's transform at the SIMD's issue port (an MFMA holds it for 8 of its 32
+        // cycles; the transform's vector instructions take what is left)
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) read_tile(m, 0);
 #pragma unroll
         for (int dx = 0; dx < NDX; ++dx) {
-            const int cur = dx & 1;
-            if (dx + 1 < NDX) read_rows(cur ^ 1, dx + 1);
-            // the rotation below keeps the CURRENT step's fragments in w3[0] (pass is a run-time value, so the slot of a
-            // step cannot be a compile-time index: rotate instead -- register renaming inside the unrolled pass)
+            const int sl = (PAR + dx) & 1;
+            const bool more_w = !(dx == NDX - 1) || !last_pass;     // a step follows (run-time only for the last dx)
+            if (dx + 1 < NDX) load_w(sl ^ 1);
+            else if (more_w) load_w(sl ^ 1);
+            // the last step has no operand reads to issue: the next transform's columns start their trip from HBM here
+            if (PREFETCH && dx == NDX - 1) t_load(prefetch_pass, 0, dpre, tsx);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {                           // one operand stays put between neighbours
-                acc[m][0] = mfma16(fa[cur][m][1], w3[0][0][0], acc[m][0]);      // Vl Uh0
-                acc[m][1] = mfma16(fa[cur][m][1], w3[0][0][1], acc[m][1]);      // Vl Uh1
-                acc[m][1] = mfma16(fa[cur][m][0], w3[0][1][1], acc[m][1]);      // Vh Ul1
-                acc[m][0] = mfma16(fa[cur][m][0], w3[0][1][0], acc[m][0]);      // Vh Ul0
-                acc[m][0] = mfma16(fa[cur][m][0], w3[0][0][0], acc[m][0]);      // Vh Uh0
-                acc[m][1] = mfma16(fa[cur][m][0], w3[0][0][1], acc[m][1]);      // Vh Uh1
-            }
-            // rotate: slot 0 <- slot 1 <- slot 2 <- fragments of step + 3
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    w3[0][pl][n] = w3[1][pl][n];
-                    w3[1][pl][n] = w3[2][pl][n];
-                }
-            {
-                const int nxt = min(pass * NDX + dx + 3, NSTEP - 1);   // clamped: a harmless re-load at the end
-                load_w(2, nxt);
-            }
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              // MFMA
-                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // weight fragment load
-                else if (dx + 1 < NDX) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // operand read
+                acc[m][0] = mfma16(fa[m][1], w2[sl][0][0], acc[m][0]);      // Vl Uh0
+                acc[m][1] = mfma16(fa[m][1], w2[sl][0][1], acc[m][1]);      // Vl Uh1
+                acc[m][1] = mfma16(fa[m][0], w2[sl][1][1], acc[m][1]);      // Vh Ul1
+                acc[m][0] = mfma16(fa[m][0], w2[sl][1][0], acc[m][0]);      // Vh Ul0
+                acc[m][0] = mfma16(fa[m][0], w2[sl][0][0], acc[m][0]);      // Vh Uh0
+                acc[m][1] = mfma16(fa[m][0], w2[sl][0][1], acc[m][1]);      // Vh Uh1
+                if (dx + 1 < NDX) read_tile(m, dx + 1);
+                // fence: left alone, the scheduler sinks these reads to just in front of their use one step later (one
+                // register pair for all four tiles, LDS latency exposed every six MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
-    __syncthreads();                            // the V image is dead: exchange area
+        __builtin_amdgcn_s_setprio(0);
+    };
 
-    // ---- the eight M_xi meet: round tq = 4-row group.  Writer layout = reader layout (lane-preserving).
+    // Waves w and w + 4 share a SIMD.  Waves 0-3 transform pass p + 1 BEFORE they multiply pass p, waves 4-7 AFTER: on
+    // every SIMD one wave's vector-ALU / load phase runs under the other wave's matrix phase.
+    const bool early = wave < 4;
+    if (!wide) {                                // zero padding left and right of a full-width tile, both images
+        const int im = t >> 8, row = (t >> 4) & 15, cc = (t >> 2) & 3, ch = t & 3;
+        *reinterpret_cast<f32x4*>(lds + im * IMG_BYTES + ((row * IW + (cc < 2 ? cc : 64 + cc)) << 6) + ch * 16) =
+            f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    transform(0, lds, false);
+    if (PREFETCH && early) t_load(1, 0, dpre, tsx);     // the early waves hold the columns of pass m + 1 when pass m multiplies
+    WINO_T(0);
+    __syncthreads();
+    WINO_T(2);
+#pragma unroll 1
+    for (int pp = 0; pp < NPASS; pp += 2) {
+        // pass pp on image 0 (image 1 receives pass pp + 1), then pass pp + 1 on image 1 (image 0 receives pass pp + 2).
+        // The last step of a multiply issues the loads of the transform the wave runs next: pass m + 2 on the early
+        // waves (m = the pass being multiplied), m + 1 on the late ones.
+        if (early) transform(pp + 1, lds + IMG_BYTES, true);
+        WINO_T(0);
+        multiply(std::integral_constant<int, 0>{}, false, early ? pp + 2 : pp + 1);
+        WINO_T(1);
+        if (!early) transform(pp + 1, lds + IMG_BYTES, true);
+        WINO_T(0);
+        __syncthreads();                        // image 1 complete, image 0 free
+        WINO_T(2);
+        const bool more = pp + 2 < NPASS;
+        if (early && more) transform(pp + 2, lds, true);
+        WINO_T(0);
+        multiply(std::integral_constant<int, 1>{}, !more, early ? pp + 3 : pp + 2);
+        WINO_T(1);
+        if (!early && more) transform(pp + 2, lds, true);
+        WINO_T(0);
+        __syncthreads();
+        WINO_T(2);
+    }
+
+    // ---- the eight M_xi meet: round tq = 4-row group.  Writer layout = reader layout (lane-preserving): wave xi writes
+    // its four tiles (pixel half, channel half) as quads of registers; wave w then reads, for pixel half w / 4 and register
+    // quad g = w % 4, the same quad of all eight xi and both channel halves (16 reads) and forms ALL FOUR output rows:
+    // y[n][4 a + e] = row 4 tq + a, column 32 xh + 8 g + 4 h + e, channel 32 n + l31 -- "pixel slot" 8 a + 4 h + e.
     float* const xch = reinterpret_cast<float*>(lds);
-    const int oa = wave >> 1, oxh = wave & 1;   // this wave's output row inside the group / 32-pixel half
+    const int oxh = wave >> 2, og = wave & 3;
     constexpr int SS = C + 4;
-    float coef[NXI];
-#pragma unroll
-    for (int q = 0; q < NXI; ++q) coef[q] = p.coef[oa * NXI + q];
 
 #pragma unroll
     for (int tq = 0; tq < NT_ROWS; ++tq) {
@@ -262,7 +359,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
                     *reinterpret_cast<f32x4*>(xch + ((((wave * 4 + xh * 2 + n) * 4 + g) * 64 + lane) << 2)) =
                         f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
                 }
+        WINO_T(3);
         __syncthreads();
+        WINO_T(4);
         f32x16 y[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -271,16 +370,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
 #pragma unroll
         for (int q = 0; q < NXI; ++q)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xch + ((((q * 4 + oxh * 2 + n) * 4 + og) * 64 + lane) << 2));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(xch + ((((q * 4 + oxh * 2 + n) * 4 + g) * 64 + lane) << 2));
+                for (int a = 0; a < 4; ++a) {
+                    const float cf = p.coef[a * NXI + q];
+                    if (a == 0 ? q == 7 : q == 0) continue;             // AT[0][7] = AT[1..3][0] = 0
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[n][4 * g + e] = fmaf(coef[q], v[e], y[n][4 * g + e]);
+                    for (int e = 0; e < 4; ++e) y[n][4 * a + e] = fmaf(cf, v[e], y[n][4 * a + e]);
                 }
+            }
+        WINO_T(5);
         __syncthreads();                        // everyone has read: the area becomes eight wave-private stages
+        WINO_T(6);
 
-        const int oy = ty0 + 4 * tq + oa, ox = tx0 + oxh * 32;
+        // pixel slot s = 8 a + c (c = 4 h + e): image row 4 tq + (s >> 3), column 32 xh + 8 g + (s & 7)
+        const int oy0 = ty0 + 4 * tq, ox = tx0 + oxh * 32 + og * 8;
         if constexpr (TAILP) {
             // the decoder tail folded in, as in conv_f16x3.hip (TAILP): 36 tap products per pixel leave the chip
             typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -352,12 +457,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
                 const int idx = lane + 64 * it;
                 if (idx < 36 * 8) {
                     const int to = idx >> 3, c4 = (idx & 7) * 4;
-                    *reinterpret_cast<f32x4*>(pout + ((size_t)to * p.H + oy) * p.W + ox + c4) =
+                    *reinterpret_cast<f32x4*>(pout + ((size_t)to * p.H + oy0 + (c4 >> 3)) * p.W + ox + (c4 & 7)) =
                         *reinterpret_cast<const f32x4*>(pst + to * TPS + c4);
                 }
             }
         } else {
-            // through a wave-private LDS stage: 16-byte stores, 32 pixels x 64 channels
+            // through a wave-private LDS stage: 16-byte stores, 32 pixel slots (4 rows x 8 columns) x 64 channels
             float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SS);
             const float oscale = p.out_mode == 1 ? VS : 1.f;
 #pragma unroll
@@ -384,7 +489,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
                         hi[u] = (_Float16)X;
                         lo[u] = (_Float16)(X - (float)hi[u]);
                     }
-                    unsigned char* blk = ybase + (((size_t)plane * p.H + oy) * p.W + ox + px) * 64 + cq * 2;
+                    unsigned char* blk = ybase + (((size_t)plane * p.H + oy0 + (px >> 3)) * p.W + ox + (px & 7)) * 64 + cq * 2;
                     *reinterpret_cast<f16x4*>(blk) = hi;
                     *reinterpret_cast<f16x4*>(blk + OFF_LO) = lo;
                 }
@@ -394,20 +499,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs p
                 for (int it = 0; it < 8; ++it) {
                     const int plane = it >> 1, px = (it & 1) * 16 + (lane >> 2), cq = (lane & 3) * 4;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
-                    *reinterpret_cast<f32x4*>(ybase + (((size_t)plane * p.H + oy) * p.W + ox + px) * CCH + cq) = v;
+                    *reinterpret_cast<f32x4*>(ybase + (((size_t)plane * p.H + oy0 + (px >> 3)) * p.W + ox + (px & 7)) * CCH + cq) = v;
                 }
             } else {
-                float* yrow = p.y + (((size_t)img * p.H + oy) * p.W + ox) * C;
+                float* ybase = p.y + (size_t)img * p.H * p.W * C;
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int idx = lane + 64 * it;
                     const int px = idx >> 4, c4 = (idx & 15) * 4;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
-                    *reinterpret_cast<f32x4*>(yrow + (size_t)px * C + c4) = v;
+                    *reinterpret_cast<f32x4*>(ybase + (((size_t)(oy0 + (px >> 3))) * p.W + ox + (px & 7)) * C + c4) = v;
                 }
             }
         }
+        WINO_T(7);
     }
+#ifdef TOCVP_WINO_STAMP
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long* o = tocvp_wino_stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 16;
+        for (int i = 0; i < 12; ++i) o[i] = stamp_acc[i];
+        o[14] = stamp_first;
+        o[15] = stamp_last;
+    }
+#endif
 }
 
 
