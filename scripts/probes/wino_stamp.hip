@@ -1,5 +1,5 @@
-// Where a workgroup of the Winograd decoder conv spends its cycles: s_memtime stamps of waves 0 (transforms the next pass
-// BEFORE it multiplies) and 4 (AFTER) at the phase boundaries.
+// Where a workgroup of the Winograd decoder conv spends its cycles: s_memtime stamps of waves 0 and 3 at the phase boundaries
+// (-DTOCVP_WINO_STAMP), or the launch time with one part of the kernel taken out (-DTOCVP_WINO_ABLATE=1..4, no stamps).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itextocvp_amd/csrc -DTOCVP_WINO_STAMP \
 //         -o scripts/probes/wino_stamp scripts/probes/wino_stamp.hip ;  ./wino_stamp [nimg]
 #include "../../textocvp_amd/csrc/conv_wino.hip"
@@ -29,18 +29,19 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); for (int i = 0; i < 5; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int nwg = std::min(16384, ((n + 7) / 8) * 8 * 8);
+    printf("%d slot images: %.3f ms per launch (TOCVP_WINO_ABLATE %d)\n", n, ms / 5, TOCVP_WINO_ABLATE);
+#ifdef TOCVP_WINO_STAMP
+    const int nwg = std::min(16384, ((n + 7) / 8) * 8 * 16);
     std::vector<unsigned long long> st((size_t)16384 * 2 * 16);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(tocvp_wino_stamps), st.size() * 8);
-    const char* names[12] = {"transform: rest", "multiply (4 passes)", "pass barriers", "exchange write", "exchange barrier 1",
-                             "read + combine", "exchange barrier 2", "epilogue + stores", "transform: load issue (unprefetched)",
-                             "transform: wait for the loads", "transform: arithmetic + LDS stores issued", "transform: LDS stores landed"};
+    const char* names[8] = {"transform (4 passes)", "multiply (4 passes)", "pass barriers", "exchange write", "exchange barrier 1",
+                            "read + combine", "exchange barrier 2", "epilogue + stores"};
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     printf("%d slot images: %.3f ms per launch, %d workgroups\n", n, ms / 5, nwg);
     for (int half = 0; half < 2; ++half) {
         double tot = 0;
-        printf(" wave %d (%s)\n", half * 4, half ? "multiplies, then transforms the next pass" : "transforms the next pass, then multiplies");
-        for (int ph = 0; ph < 12; ++ph) {
+        printf(" wave %d\n", half * 3);
+        for (int ph = 0; ph < 8; ++ph) {
             std::vector<double> v;
             for (int i = 0; i < nwg; ++i) v.push_back((double)st[((size_t)i * 2 + half) * 16 + ph]);
             printf("   %-44s median %8.0f ticks\n", names[ph], med(v));
@@ -50,5 +51,6 @@ int main(int argc, char** argv) {
         for (int i = 0; i < nwg; ++i) life.push_back((double)(st[((size_t)i * 2 + half) * 16 + 15] - st[((size_t)i * 2 + half) * 16 + 14]));
         printf("   sum %.0f; lifetime median %.0f ticks (100 MHz: x 10 ns)\n", tot, med(life));
     }
+#endif
     return 0;
 }
