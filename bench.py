@@ -659,8 +659,8 @@ def main():
                         conv["units"] / conv["launches"]) / rec["slot_images_per_launch"]
                     traffic_from = "profiles/conv_pmc_summary.json (rocprofv3 PMC on scripts/decode_only.py, separate " \
                                    "FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; launch-weighted mean of " \
-                                   "the three instances the timed tree runs -- layer 1 collapsed input, layer 2 planes " \
-                                   "in / out, layer 3 planes in + folded tail out; " \
+                                   "the three instances the timed tree runs -- layer 1 collapsed input, layer 2 " \
+                                   "activations in / out, layer 3 activations in + folded tail out; " \
                                    f"{rec.get('hbm_over_algorithmic', 0):.2f} x the algorithmic bytes; not this run)"
             roofline = {"bound": "mfma", "kernel": kernel_name,
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -682,9 +682,9 @@ def main():
                         "note": "achieved / avg_launch_ms are IN SITU (HIP events inside the second timed region: the "
                                 "same K steps without the decode / rollout overlap, value_no_overlap; "
                                 "algorithmic 0.839 GFLOP per slot image and layer, + 0.019 in the last layer, whose epilogue "
-                                "also applies the decoder tail's taps); frac prices ALGORITHMIC flops "
-                                "against the dense f16 peak, frac_executed_mfma counts the matrix products the "
-                                "split arithmetic really issues"}
+                                "also applies the decoder tail's taps); frac prices ALGORITHMIC flops (those of the "
+                                "reference's direct convolution) against the dense f16 peak, frac_executed_mfma counts the "
+                                "matrix products the kernel really issues (split arithmetic x 3, Winograd x 0.4)"}
             rooflines.append(roofline)
         if timer_all is not None:
             summ = timer_all.summary()

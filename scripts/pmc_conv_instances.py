@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """
-HBM traffic per launch of EVERY instance of the decoder convolution as the timed tree runs it (round 4):
+HBM traffic per launch of EVERY instance of the decoder convolution as the timed tree runs it (round 4; round 5: the
+Winograd kernel, `python scripts/pmc_conv_instances.py --wino ...`):
 
     conv5x5_dec_f16x3_kernel<1, false, false>   layer 1: collapsed layer-0 input, operand planes out
     conv5x5_dec_f16x3_kernel<0, true, false>    layer 2: operand planes in and out
     conv5x5_dec_f16x3_kernel<0, true, true>     layer 3: operand planes in, the folded tail's 36 tap planes out
+    conv5x5_wino_f16x3_kernel<1, false> / <0, false> / <0, true>   the same three layers (fp32 x 16 hand-over)
 
 from two rocprofv3 PMC passes over `python3 scripts/decode_only.py 68 3` (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, the
 program directly behind `--`; corrections of /opt/skills/guides/MI355X_MICROARCH.md, section HBM:
@@ -28,21 +30,34 @@ INSTANCES = {
 }
 
 
+WINO_INSTANCES = {
+    "<1, false>": {"layer": 1, "alg_in": 25 * 64 * 4.0, "alg_out": MIB, "shared_in": MIB},
+    "<0, false>": {"layer": 2, "alg_in": MIB, "alg_out": MIB, "shared_in": 0.0},
+    "<0, true>": {"layer": 3, "alg_in": MIB, "alg_out": 36 * 4096 * 4.0, "shared_in": 0.0},
+}
+KERNEL = "conv5x5_dec_f16x3_kernel"
+TILES_PER_IMAGE = 8.0                                               # 8 x 64 tiles of a 64 x 64 slot image
+
+
 def per_instance(path, counter):
     out = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or "conv5x5_dec_f16x3_kernel" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != counter or KERNEL not in r["Kernel_Name"]:
             continue
         for key in INSTANCES:
-            if "conv5x5_dec_f16x3_kernel" + key in r["Kernel_Name"].replace("kernel <", "kernel<"):
+            if KERNEL + key in r["Kernel_Name"].replace("kernel <", "kernel<"):
                 out.setdefault(key, []).append((int(r["Grid_Size"]), int(r["Workgroup_Size"]), float(r["Counter_Value"])))
     return out
 
 
 def main():
+    global INSTANCES, KERNEL, TILES_PER_IMAGE
+    if sys.argv[1] == "--wino":
+        INSTANCES, KERNEL, TILES_PER_IMAGE = WINO_INSTANCES, "conv5x5_wino_f16x3_kernel", 16.0     # 4 x 64 tiles
+        sys.argv.pop(1)
     fpath, wpath, out = sys.argv[1:4]
     fetch, write = per_instance(fpath, "FETCH_SIZE"), per_instance(wpath, "WRITE_SIZE")
-    rec = {"kernel": "conv5x5_dec_f16x3_kernel (f16x3), the three instances of the default decoder",
+    rec = {"kernel": KERNEL + (" (f16x3-wino)" if "wino" in KERNEL else " (f16x3)") + ", the three instances of the default decoder",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 1/2 of wide "
                          "coalesced reads; KiB units); separate --pmc passes", "instances": {}}
     tot_hbm = tot_alg = 0.0
@@ -54,7 +69,7 @@ def main():
         fv = [v for g, _, v in f if g == gmax]
         wv = [v for g, _, v in w if g == gmax]
         wgs = gmax // f[0][1]
-        images = wgs / 8.0                                          # eight 8 x 64 tiles per 64 x 64 slot image
+        images = wgs / TILES_PER_IMAGE
         hbm = (2.0 * sum(fv) / len(fv) + sum(wv) / len(wv)) * 1024.0
         alg = images * (spec["alg_in"] + spec["alg_out"]) + spec["shared_in"]
         rec["instances"][key] = {
