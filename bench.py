@@ -115,6 +115,7 @@ class ClockSampler:
             want = f":{int(pci_bus_id):02x}:"
             hit = [n for n in nodes if want in os.path.realpath(os.path.dirname(os.path.dirname(os.path.dirname(n))))]
             nodes = hit or nodes
+        self.power_path, self.power = None, []
         for n in nodes:
             try:
                 int(open(n).read())
@@ -122,17 +123,28 @@ class ClockSampler:
                 break
             except (OSError, ValueError):
                 continue
+        if self.path is not None:                      # board power next to it (microwatts), where the node exists
+            for name in ("power1_average", "power1_input"):
+                cand = os.path.join(os.path.dirname(self.path), name)
+                try:
+                    int(open(cand).read())
+                    self.power_path = cand
+                    break
+                except (OSError, ValueError):
+                    continue
 
     def start(self):
         if self.path is None:
             return
         import threading
-        self.samples, self._stop = [], False
+        self.samples, self.power, self._stop = [], [], False
 
         def loop():
             while not self._stop:
                 try:
                     self.samples.append(int(open(self.path).read()) / 1e6)
+                    if self.power_path is not None:
+                        self.power.append(int(open(self.power_path).read()) / 1e6)
                 except (OSError, ValueError):
                     pass
                 time.sleep(0.005)
@@ -149,8 +161,11 @@ class ClockSampler:
         if not self.samples:
             return None
         v = self.samples
-        return {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "samples": len(v),
-                "source": self.path}
+        out = {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "samples": len(v),
+               "source": self.path}
+        if self.power:
+            out["board_power_w"] = {"mean": round(sum(self.power) / len(self.power), 1), "max": round(max(self.power), 1)}
+        return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -66,7 +66,8 @@ struct WArgs {
     int nimg, H, W, relu;
     int out_mode;                   // 0 fp32 NHWC; 1 fp32 x 16, pass-major (n, 4, H, W, 16); 2 fp16 operand planes of 2^8 y, pass-major
     const unsigned char* tail_wf;   // TAILP: tap matrix of the folded decoder tail (conv_f16x3.hip: pack_tail_taps_kernel)
-    float coef[4 * NXI];            // AT[a][xi] / (VS * s_xi)
+    float coef[4 * NXI];            // oscale * AT[a][xi] / (VS * s_xi)
+    float oscale;                   // scale of the output buffer: 16 (out_mode 1), 256 (operand planes, folded tail), 1 (NHWC)
 };
 
 #ifndef TOCVP_WINO_ABLATE
@@ -94,6 +95,17 @@ __device__ __forceinline__ int border_class(int p, int n) {
 }
 
 __device__ __forceinline__ float clampf(float v, float m) { return __builtin_amdgcn_fmed3f(v, -m, m); }
+
+// Two values -> their fp16 planes (hi = f16(clamp x), lo = f16(x - hi), packed pairs) in five instructions: the compiler's
+// form of the same arithmetic takes 8.5 (it converts hi twice and back once).  The mixed-precision FMA subtracts in fp32 and
+// rounds once: bit-identical to (_Float16)(X - (float)hi) (checked on 128 values incl. saturating and tiny ones).
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    x0 = clampf(x0, F16MAX);
+    x1 = clampf(x1, F16MAX);
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+}
 
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
     if (TOCVP_WINO_ABLATE == 4) {               // keeps the operands alive, issues no matrix instruction
@@ -124,23 +136,20 @@ __device__ __forceinline__ void wino_epilogue(const WArgs& p, f32x16 (&y)[2], un
         const unsigned char* trd = timg + (8 * h + (i16 >> 2)) * 64 + (c16 + 4 * (i16 & 3)) * 2;
         const f16x8* twf = reinterpret_cast<const f16x8*>(p.tail_wf) + lane;
         float* pout = p.y + (size_t)img * 36 * p.H * p.W;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const float bv = p.bias[n * 32 + l31];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 hi, lo;
+            for (int g = 0; g < 4; ++g) {                           // y carries bias and the planes' 2^8 already
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = y[n][4 * g + e] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    const float X = clampf(v * SA8, F16MAX);
-                    hi[e] = (_Float16)X;
-                    lo[e] = (_Float16)(X - (float)hi[e]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = p.relu ? fmaxf(y[n][4 * g + e], 0.f) : y[n][4 * g + e];
+                unsigned h0, l0, h1, l1;
+                split2(v[0], v[1], h0, l0);
+                split2(v[2], v[3], h1, l1);
                 unsigned char* dd = timg + (n * 32 + l31) * 64 + (8 * g + 4 * h) * 2;
-                *reinterpret_cast<f16x4*>(dd) = hi;
-                *reinterpret_cast<f16x4*>(dd + TIMG) = lo;
+                *reinterpret_cast<u32x2*>(dd) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(dd + TIMG) = u32x2{l0, l1};
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -189,17 +198,11 @@ __device__ __forceinline__ void wino_epilogue(const WArgs& p, f32x16 (&y)[2], un
     } else {
         // through a wave-private LDS stage: 16-byte stores, 32 pixel slots (4 rows x 8 columns) x 64 channels
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * SS);
-        const float oscale = p.out_mode == 1 ? VS : 1.f;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const float bv = p.bias[n * 32 + l31];
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = y[n][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                stage[acc_row(r, h) * SS + n * 32 + l31] = v * oscale;
-            }
-        }
+            for (int r = 0; r < 16; ++r)                            // y carries bias and the output buffer's scale already
+                stage[acc_row(r, h) * SS + n * 32 + l31] = p.relu ? fmaxf(y[n][r], 0.f) : y[n][r];
         __builtin_amdgcn_wave_barrier();
         if (p.out_mode == 2) {
             unsigned char* ybase = reinterpret_cast<unsigned char*>(p.y + (size_t)img * p.H * p.W * C);
@@ -207,16 +210,13 @@ __device__ __forceinline__ void wino_epilogue(const WArgs& p, f32x16 (&y)[2], un
             for (int it = 0; it < 8; ++it) {
                 const int plane = it >> 1, px = (it & 1) * 16 + (lane >> 2), cq = (lane & 3) * 4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + plane * CCH + cq);
-                f16x4 hi, lo;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float X = clampf(v[u] * TOCVP_F16X3_ACT_SCALE, F16MAX);
-                    hi[u] = (_Float16)X;
-                    lo[u] = (_Float16)(X - (float)hi[u]);
-                }
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                unsigned h0, l0, h1, l1;
+                split2(v[0], v[1], h0, l0);
+                split2(v[2], v[3], h1, l1);
                 unsigned char* blk = ybase + (((size_t)plane * p.H + oy0 + (px >> 3)) * p.W + ox + (px & 7)) * 64 + cq * 2;
-                *reinterpret_cast<f16x4*>(blk) = hi;
-                *reinterpret_cast<f16x4*>(blk + OFF_LO) = lo;
+                *reinterpret_cast<u32x2*>(blk) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(blk + OFF_LO) = u32x2{l0, l1};
             }
         } else if (p.out_mode == 1) {
             float* ybase = p.y + (size_t)img * p.H * p.W * C;
@@ -325,8 +325,6 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
         const bool xin = ix >= 0 && ix < p.W;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int iy = ty0 - 2 + i;
-            const bool inside = xin && iy >= 0 && iy < p.H;
             if (MODE == 1) {
                 d[i] += ts[i];
 #pragma unroll
@@ -334,7 +332,13 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
             } else if (MODE == 2) {
                 d[i] *= VS;
             }
-            if (!inside) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // zero padding: only the first and last two rows of the 8 can lie above / below the image; columns beside it
+            // exist only for the halo columns of wide images (rep 1)
+            if (i < 2 || i >= 6 || rep) {
+                const int iy = ty0 - 2 + i;
+                const bool inside = (xin || !rep) && iy >= 0 && iy < p.H;
+                if (!inside) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         f32x4 v[8];
         v[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
@@ -354,18 +358,15 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
             v[5] = e + o;
             v[6] = e - o;
         }
-        unsigned char* dst = lds + (xi << 6) + ((((cq >> 1) ^ (xi >> 2)) & 3) << 4) + (cq & 1) * 8;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const int off = (xi << 6) + ((((cq >> 1) ^ (xi >> 2)) & 3) << 4) + (cq & 1) * 8;      // Vh; Vl at off ^ 32 (rows are 4352 B apart)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            f16x4 hi, lo;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float X = clampf(v[q][u], F16MAX);
-                hi[u] = (_Float16)X;
-                lo[u] = (_Float16)(X - (float)hi[u]);
-            }
-            *reinterpret_cast<f16x4*>(dst + q * IW * 64) = hi;
-            *reinterpret_cast<f16x4*>((unsigned char*)((size_t)(dst + q * IW * 64) ^ 32)) = lo;
+            unsigned h0, l0, h1, l1;
+            split2(v[q][0], v[q][1], h0, l0);
+            split2(v[q][2], v[q][3], h1, l1);
+            *reinterpret_cast<u32x2*>(lds + off + q * IW * 64) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(lds + (off ^ 32) + q * IW * 64) = u32x2{l0, l1};
         }
     };
     f32x4 dpre[8];
@@ -485,11 +486,13 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
         WINO_T(3);
         __syncthreads();
         WINO_T(4);
-        f32x16 y[2];
+        f32x16 y[2];                            // starts from the bias (x the output buffer's scale, as the coefficients)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n) {
+            const float b0 = p.bias[n * 32 + l31] * p.oscale;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) y[n][q] = 0.f;
+            for (int q = 0; q < 16; ++q) y[n][q] = b0;
+        }
 #pragma unroll
         for (int q = 0; q < NXI; ++q)
 #pragma unroll
@@ -603,8 +606,9 @@ extern "C" int tocvp_conv5x5_dec_wino_f16x3_f32(const float* x, const float* aux
         return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     WArgs a{x, aux, static_cast<const unsigned char*>(wf), bias, y, nimg, H, W, relu, out_mode,
-            static_cast<const unsigned char*>(tail_taps), {}};
-    for (int i = 0; i < 4 * NXI; ++i) a.coef[i] = coef[i];
+            static_cast<const unsigned char*>(tail_taps), {}, 1.f};
+    a.oscale = out_mode == 1 ? VS : (out_mode >= 2 ? TOCVP_F16X3_ACT_SCALE : 1.f);      // exact powers of two
+    for (int i = 0; i < 4 * NXI; ++i) a.coef[i] = coef[i] * a.oscale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((size_t)((nimg + 7) / 8) * 8 * (H / W4_TH) * (W / TW)));
     const dim3 block(W4_THREADS);
