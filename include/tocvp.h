@@ -385,14 +385,18 @@ int tocvp_conv5x5_dec_f16x3_f32(const float* x, const float* aux, int in_mode, c
  *   out_mode: 0 fp32 NHWC; 1 fp32 x 16 pass-major; 2 fp16 operand planes of 2^8 y, pass-major (the planes input of
  *   tocvp_conv5x5_dec_f16x3_f32 / _tail_f32); 3 (tail_taps != NULL, else NULL) y = (nimg, 36, H, W) tap products of the
  *   folded decoder tail (tocvp_pack_tail_taps_f16x3, summed by tocvp_dec_tail_sum_f32).
- * H % 8 == 0, W % 64 == 0.  Valid for |x| < 255 (operands saturate beyond); no limit on the weights.
+ *   in_amax (in_mode 2, nullable): DEVICE word holding max |x| as tocvp_absmax_f32 writes it -- the input is then scaled by the
+ *   largest power of two that keeps it inside the fp16 planes instead of by 16: inputs of any magnitude (the data gradients of
+ *   the training step, 04_train_predictor.py); gate (out_mode 0, nullable): NHWC array, outputs are zeroed where gate <= 0
+ *   (the ReLU of the layer below in the backward pass).
+ * H % 4 == 0, W % 64 == 0.  Valid for |x| < 255 without in_amax (operands saturate beyond); no limit on the weights.
  * ------------------------------------------------------------------------------------------- */
 size_t tocvp_conv_weights_wino_f16x3_bytes(void);
 int tocvp_split_conv_weights_wino_f16x3(const float* w, void* wf, const float* scales, float* absmax_out, int Cout,
                                         int Cin, void* stream);
 int tocvp_conv5x5_dec_wino_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf, const float* coef,
                                      const float* bias, const void* tail_taps, float* y, int nimg, int H, int W,
-                                     int relu, int out_mode, void* stream);
+                                     int relu, int out_mode, const float* in_amax, const float* gate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder tail folded into the last hidden layer.  The tail Conv2d(64 -> 4, k = 3) (decoders.py:112-117) is linear,

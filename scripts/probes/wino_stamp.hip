@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 8; ++i) scales[i] = 65536.f;
     for (int i = 0; i < 32; ++i) coef[i] = 1.f / (16.f * 65536.f);
     if (tocvp_split_conv_weights_wino_f16x3(w, wf, scales, nullptr, 64, 64, nullptr)) { printf("split failed\n"); return 1; }
-    auto run = [&]() { return tocvp_conv5x5_dec_wino_f16x3_f32(x, nullptr, 0, wf, coef, b, nullptr, y, n, H, W, 1, 1, nullptr); };
+    auto run = [&]() { return tocvp_conv5x5_dec_wino_f16x3_f32(x, nullptr, 0, wf, coef, b, nullptr, y, n, H, W, 1, 1, nullptr, nullptr, nullptr); };
     for (int i = 0; i < 3; ++i) if (run()) { printf("launch failed\n"); return 1; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); for (int i = 0; i < 5; ++i) run(); hipEventRecord(e1); hipEventSynchronize(e1);

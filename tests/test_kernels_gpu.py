@@ -747,6 +747,17 @@ def test_conv5x5_dec_wino_collapsed_tail_and_wide_weights():
         e = (g_.cpu().double() - r_.reshape(g_.shape)).abs().max().item()
         print(f"Winograd folded tail {name}: err {e:.2e}")
         assert e < 3e-6 * max(1.0, r_.abs().max().item())
+    # inputs of any magnitude (data gradients): the operand scale follows max |x| measured on the device; ReLU gate in the store
+    gsmall = rnd("wgs", (3, 64, 64, 64)) * 3e-6
+    gsmall[0, 7, 9, :4] = torch.tensor([4e-3, -2e-9, 1e-12, 0.0])
+    gate = rnd("wgate", (3, 64, 64, 64))
+    zb = torch.zeros(64)
+    got_g = k.conv5x5_dec_wino(gsmall.to(DEV), wp, zb.to(DEV), relu=False, auto_scale=True, gate=gate.to(DEV))
+    ref_g = F.conv2d(gsmall.permute(0, 3, 1, 2).double(), w1.double(), None, padding=2).permute(0, 2, 3, 1) * (gate > 0)
+    err_g = (got_g.cpu().double() - ref_g).abs().max().item()
+    print(f"Winograd conv on 1e-6-sized input with device-side scale: err {err_g:.2e} at scale {ref_g.abs().max().item():.2e}")
+    assert err_g < 1e-5 * ref_g.abs().max().item()           # a 1300 x outlier sets the scale; bf16x3 (the form it replaces): ~1e-4
+    assert torch.equal(got_g.cpu() == 0, (gate <= 0) | (got_g.cpu() == 0))
     # weights of any range
     w_big = w1 * 3000.0
     got_big = k.conv5x5_dec_wino(x0.permute(0, 2, 3, 1).contiguous().to(DEV)[:, :, :, :64].contiguous(),

@@ -68,6 +68,9 @@ struct WArgs {
     const unsigned char* tail_wf;   // TAILP: tap matrix of the folded decoder tail (conv_f16x3.hip: pack_tail_taps_kernel)
     float coef[4 * NXI];            // oscale * AT[a][xi] / (VS * s_xi)
     float oscale;                   // scale of the output buffer: 16 (out_mode 1), 256 (operand planes, folded tail), 1 (NHWC)
+    const float* in_amax;           // MODE 2, nullable: device word holding max |x| -- the kernel scales the input by the largest power
+                                    // of two that keeps 15 |x| inside fp16 instead of by 16 (data gradients: any magnitude)
+    const float* gate;              // out_mode 0, nullable: NHWC array, the output is zeroed where gate <= 0 (ReLU of the layer below)
 };
 
 #ifndef TOCVP_WINO_ABLATE
@@ -232,8 +235,14 @@ __device__ __forceinline__ void wino_epilogue(const WArgs& p, f32x16 (&y)[2], un
             for (int it = 0; it < 8; ++it) {
                 const int idx = lane + 64 * it;
                 const int px = idx >> 4, c4 = (idx & 15) * 4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
-                *reinterpret_cast<f32x4*>(ybase + (((size_t)(oy0 + (px >> 3))) * p.W + ox + (px & 7)) * C + c4) = v;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * SS + c4);
+                const size_t o = (((size_t)(oy0 + (px >> 3))) * p.W + ox + (px & 7)) * C + c4;
+                if (p.gate) {
+                    const f32x4 gt = *reinterpret_cast<const f32x4*>(p.gate + (size_t)img * p.H * p.W * C + o);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = gt[u] > 0.f ? v[u] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(ybase + o) = v;
             }
         }
     }
@@ -258,6 +267,13 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
     if (img >= p.nimg) return;
     const int ty0 = (tile / tiles_x) * W4_TH, tx0 = (tile % tiles_x) * TW;
     const bool wide = p.W != TW;
+    // scale of the (MODE 2) input: 16, or the power of two <= 4096 / max |x| (|BT| row sums <= 15: 15 * 4096 < 65504)
+    float in_s = VS;
+    if (MODE == 2 && p.in_amax) {
+        const float r = 4096.f / fmaxf(*p.in_amax, 1.0e-30f);
+        in_s = __uint_as_float(__float_as_uint(r) & 0x7f800000u);
+    }
+    const float csc = VS / in_s;                // the coefficients were built for a x 16 input
 
     f32x16 acc[2][2][2];                        // [j: xi = 2 wave + j][32-pixel half][32-channel half]
 #pragma unroll
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
 #pragma unroll
                 for (int u = 0; u < 4; ++u) d[i][u] = fmaxf(d[i][u], 0.f) * VS;
             } else if (MODE == 2) {
-                d[i] *= VS;
+                d[i] *= in_s;
             }
             // zero padding: only the first and last two rows of the 8 can lie above / below the image; columns beside it
             // exist only for the halo columns of wide images (rep 1)
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xch + ((((q * 2 + n) * 4 + wave) * 64 + lane) << 2));
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const float cf = p.coef[a * NXI + q];
+                    const float cf = p.coef[a * NXI + q] * csc;
                     if (a == 0 ? q == 7 : q == 0) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[n][4 * a + e] = fmaf(cf, v[e], y[n][4 * a + e]);
@@ -593,9 +609,14 @@ extern "C" int tocvp_split_conv_weights_wino_f16x3(const float* w, void* wf, con
 // 2 fp32 NHWC.  out_mode: 0 fp32 NHWC, 1 fp32 x 16 pass-major, 2 fp16 operand planes (the planes input of
 // tocvp_conv5x5_dec_f16x3_f32 / _tail_f32), 3 (tail_taps != NULL) the (nimg, 36, H, W) tap products of the folded decoder tail.
 // coef[32] = AT[a][xi] / (16 * scales[xi]) for the scales the weights were split with (host array).
+// in_amax (in_mode 2, nullable): DEVICE word with max |x| (tocvp_absmax_f32) -- inputs of any magnitude (data gradients);
+// gate (out_mode 0, nullable): NHWC array, outputs are zeroed where gate <= 0.
 extern "C" int tocvp_conv5x5_dec_wino_f16x3_f32(const float* x, const float* aux, int in_mode, const void* wf,
                                                 const float* coef, const float* bias, const void* tail_taps, float* y,
-                                                int nimg, int H, int W, int relu, int out_mode, void* stream) {
+                                                int nimg, int H, int W, int relu, int out_mode, const float* in_amax,
+                                                const float* gate, void* stream) {
+    TOCVP_CHECK_ARG((!in_amax || in_mode == 2) && (!gate || out_mode == 0));
+    if (gate && !tocvp_aligned16(gate)) return TOCVP_EALIGN;
     TOCVP_CHECK_ARG(x && wf && coef && bias && y);
     TOCVP_CHECK_ARG(in_mode >= 0 && in_mode <= 2 && (in_mode != 1 || aux != nullptr));
     TOCVP_CHECK_ARG(out_mode >= 0 && out_mode <= 3 && ((out_mode == 3) == (tail_taps != nullptr)));
@@ -606,7 +627,7 @@ extern "C" int tocvp_conv5x5_dec_wino_f16x3_f32(const float* x, const float* aux
         return TOCVP_EALIGN;
     if (nimg == 0) return TOCVP_OK;
     WArgs a{x, aux, static_cast<const unsigned char*>(wf), bias, y, nimg, H, W, relu, out_mode,
-            static_cast<const unsigned char*>(tail_taps), {}, 1.f};
+            static_cast<const unsigned char*>(tail_taps), {}, 1.f, in_amax, gate};
     a.oscale = out_mode == 1 ? VS : (out_mode >= 2 ? TOCVP_F16X3_ACT_SCALE : 1.f);      // exact powers of two
     for (int i = 0; i < 4 * NXI; ++i) a.coef[i] = coef[i] * a.oscale;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -192,7 +192,7 @@ _SIGNATURES = {
     "tocvp_conv5x5_dec_wino_f16x3_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tocvp_conv_weights_dec_f16x3_bytes": (ctypes.c_size_t, []),
     "tocvp_split_conv_weights_dec_f16x3": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -1520,15 +1520,26 @@ def split_conv_weights_wino_f16x3(w):
     return wf, coef
 
 
-def conv5x5_dec_wino(x, wpack, bias, relu=True, out=None, collapsed=None, in_mode=2, out_mode=0, tail_taps=None):
+def conv5x5_dec_wino(x, wpack, bias, relu=True, out=None, collapsed=None, in_mode=2, out_mode=0, tail_taps=None,
+                     auto_scale=False, gate=None):
     """
     64 -> 64 5x5 conv as vertical Winograd F(4, 5) with split-fp16 products (tocvp_conv5x5_dec_wino_f16x3_f32).
     wpack = split_conv_weights_wino_f16x3(weight).  in_mode 0: x is (n, 4, H, W, 16) fp32 holding 16 * activation (what
     out_mode 1 writes), 2: NHWC fp32; collapsed = (cpos, S): first layer.  out_mode 0 NHWC fp32, 1 the x 16 pass-major
     buffer, 2 fp16 operand planes for conv5x5_dec_f16x3(_tail) (never with the range check on), 3 with tail_taps: the
     (n, 36, H, W) tap products of the folded decoder tail.
+    auto_scale (in_mode 2): max |x| is reduced on the device (tocvp_absmax_f32, no host round trip) and the kernel scales
+    the input by the matching power of two -- inputs of any magnitude, e.g. data gradients; gate (out_mode 0): the output
+    is zeroed where gate <= 0.
     """
     wf, coef = wpack
+    amax = None
+    if auto_scale:
+        assert collapsed is None and in_mode == 2
+        amax = torch.empty(1, device=x.device, dtype=torch.int32)
+        _check(lib().tocvp_absmax_f32(_ptr(x), x.numel(), _ptr(amax), _stream()), "tocvp_absmax_f32")
+    if gate is not None:
+        assert out_mode == 0 and gate.is_contiguous() and gate.dtype == torch.float32
     if collapsed is not None:
         cpos, S = collapsed
         H, W, Cin = cpos.shape
@@ -1544,7 +1555,7 @@ def conv5x5_dec_wino(x, wpack, bias, relu=True, out=None, collapsed=None, in_mod
         else:
             n, H, W, _ = x.shape
         xin, aux, mode, dev = x, None, in_mode, x.device
-        if _CHECK_RANGE:
+        if _CHECK_RANGE and not auto_scale:
             _check_f16_range(absmax(xin) * (1.0 / 16.0 if in_mode == 0 else 1.0), "conv5x5_dec_wino input")
     assert not (out_mode == 2 and _CHECK_RANGE)
     assert (out_mode == 3) == (tail_taps is not None)
@@ -1555,7 +1566,8 @@ def conv5x5_dec_wino(x, wpack, bias, relu=True, out=None, collapsed=None, in_mod
     def run():
         _check(lib().tocvp_conv5x5_dec_wino_f16x3_f32(_ptr(xin), _ptr(aux), mode, _ptr(wf),
                                                       ctypes.cast(coef, ctypes.c_void_p), _ptr(bias), _ptr(tail_taps),
-                                                      _ptr(out), n, H, W, int(bool(relu)), out_mode, _stream()),
+                                                      _ptr(out), n, H, W, int(bool(relu)), out_mode, _ptr(amax), _ptr(gate),
+                                                      _stream()),
                "tocvp_conv5x5_dec_wino_f16x3_f32")
     if TIMER is not None:
         TIMER.wrap("conv5x5_64_64", n, run)
