@@ -310,7 +310,7 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
     load_w(1);
     load_w(2);
 
-    constexpr bool PREFETCH = MODE != 1;
+    constexpr bool PREFETCH = true;             // (MODE 1: the position-table rows; its tap sums are L1 hits, loaded with the arithmetic)
     auto t_load = [&](int pass, int rep, f32x4 (&d)[8], f32x4 (&ts)[MODE == 1 ? 8 : 1]) {
         int tt = t;
         asm volatile("" : "+v"(tt));
@@ -326,19 +326,24 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
             if (MODE == 0) off = (unsigned)(((pc * p.H + iyc) * p.W + ixc) * CCH + cq * 4) * 4u;
             else off = (unsigned)((iyc * p.W + ixc) * C + c) * 4u;
             d[i] = *reinterpret_cast<const f32x4*>(xbase + off);
-            if (MODE == 1) {
-                const int cls = border_class(iyc, p.H) * 5 + border_class(ixc, p.W);
-                ts[i] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(cls * C + c) * 4u);
-            }
         }
     };
-    auto t_store = [&](int rep, f32x4 (&d)[8], f32x4 (&ts)[MODE == 1 ? 8 : 1]) {
+    auto t_store = [&](int pass, int rep, f32x4 (&d)[8], f32x4 (&ts)[MODE == 1 ? 8 : 1]) {
         int tt = t;
         asm volatile("" : "+v"(tt));
         const int cq = tt & 3, col = tt >> 2;
         const int xi = rep ? (col < 2 ? col : 64 + col) : 2 + col;
         const int ix = tx0 + xi - 2;
         const bool xin = ix >= 0 && ix < p.W;
+        if (MODE == 1) {
+            const int ixc = min(max(ix, 0), p.W - 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int iyc = min(max(ty0 - 2 + i, 0), p.H - 1);
+                const int cls = border_class(iyc, p.H) * 5 + border_class(ixc, p.W);
+                ts[i] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(cls * C + pass * CCH + cq * 4) * 4u);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (MODE == 1) {
@@ -390,10 +395,10 @@ __global__ __launch_bounds__(W4_THREADS, 2) void conv5x5_wino_f16x3_kernel(WArgs
     auto transform = [&](int pass, bool loaded) {
         if (TOCVP_WINO_ABLATE == 3) return;
         if (!PREFETCH || !loaded) t_load(pass, 0, dpre, tsx);
-        t_store(0, dpre, tsx);
+        t_store(pass, 0, dpre, tsx);
         if (wide && t < 16) {
             t_load(pass, 1, dpre, tsx);
-            t_store(1, dpre, tsx);
+            t_store(pass, 1, dpre, tsx);
         }
     };
 
