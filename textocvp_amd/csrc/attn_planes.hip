@@ -248,13 +248,12 @@ __global__ __launch_bounds__(64 * NW) void mha_planes_kernel(MhaPArgs p) {
         vfrag(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h16x8 ph, pl;
+            union { h16x8 v; unsigned u[4]; } ph_, pl_;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float P = s[8 * ks + j] * TOCVP_F16X3_ACT_SCALE;        // in [0, 256]
-                ph[j] = (_Float16)P;
-                pl[j] = (_Float16)(P - (float)ph[j]);
-            }
+            for (int j = 0; j < 8; j += 2)                                        // P in [0, 256]: no clamp
+                tocvp_split2_f16(s[8 * ks + j] * TOCVP_F16X3_ACT_SCALE, s[8 * ks + j + 1] * TOCVP_F16X3_ACT_SCALE,
+                                 ph_.u[j >> 1], pl_.u[j >> 1]);
+            const h16x8 ph = ph_.v, pl = pl_.v;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 if (2 * ks + d < 3) vfrag(2 * ks + d + 1);

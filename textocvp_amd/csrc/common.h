@@ -82,6 +82,18 @@ __device__ __forceinline__ float tocvp_gelu(float v) {
 constexpr float TOCVP_F16X3_ACT_SCALE = 256.f;
 constexpr float TOCVP_F16X3_WEIGHT_SCALE = 1024.f;
 
+// Two fp32 values -> their fp16 planes as packed pairs, hi = f16(x), lo = f16(x - hi), in three instructions
+// (v_cvt_pk_f16_f32 + two mixed-precision FMAs that subtract in fp32 and round once): bit-identical to the C expressions
+// (_Float16)x and (_Float16)(x - (float)hi), for which the compiler emits 8.5 instructions per pair (it converts hi twice
+// and back once).  The caller clamps / scales.
+__device__ __forceinline__ void tocvp_split2_f16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(x0));
+    // (the s_nop: hipcc pads nothing behind an asm statement, and an MFMA that takes `lo` as an operand right away would read
+    // the register before this vector instruction has written it -- two wait states, VALU write -> XDL read)
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(lo) : "v"(hi), "v"(x1));
+}
+
 __device__ __forceinline__ void tocvp_store_planes4(void* base, size_t elem_off, size_t plane_stride,
                                                     f32x4 v, int nsplit) {
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));

@@ -103,11 +103,7 @@ __device__ __forceinline__ float clampf(float v, float m) { return __builtin_amd
 // form of the same arithmetic takes 8.5 (it converts hi twice and back once).  The mixed-precision FMA subtracts in fp32 and
 // rounds once: bit-identical to (_Float16)(X - (float)hi) (checked on 128 values incl. saturating and tiny ones).
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    x0 = clampf(x0, F16MAX);
-    x1 = clampf(x1, F16MAX);
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+    tocvp_split2_f16(clampf(x0, F16MAX), clampf(x1, F16MAX), hi, lo);
 }
 
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
