@@ -103,16 +103,12 @@ __device__ __forceinline__ void tocvp_store_planes4(void* base, size_t elem_off,
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             v[u] = __builtin_amdgcn_fmed3f(v[u] * TOCVP_F16X3_ACT_SCALE, -65504.f, 65504.f);
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            f16x4_t piece;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                piece[u] = (_Float16)v[u];
-                v[u] -= (float)piece[u];
-            }
-            *reinterpret_cast<f16x4_t*>(ys + (size_t)sp * plane_stride) = piece;
-        }
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        unsigned h0, l0, h1, l1;                                     // hi = f16(v), lo = f16(v - hi): the same bits as the C form
+        tocvp_split2_f16(v[0], v[1], h0, l0);
+        tocvp_split2_f16(v[2], v[3], h1, l1);
+        *reinterpret_cast<u32x2_t*>(ys) = u32x2_t{h0, h1};
+        *reinterpret_cast<u32x2_t*>(ys + plane_stride) = u32x2_t{l0, l1};
     } else {
         __bf16* ys = static_cast<__bf16*>(base) + elem_off;
         for (int sp = 0; sp < nsplit; ++sp) {
