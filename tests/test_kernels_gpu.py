@@ -708,6 +708,23 @@ def test_conv5x5_dec_wino_is_fp32_class(n, HW):
     assert (plf.cpu() - want).abs().max().item() <= 2.0 ** -10 * 256.0 * 255.0 * 2.0 ** -11
 
 
+def test_conv5x5_dec_wino_rows_in_fours_and_one_image():
+    """ the Winograd entry tiles four rows at a time: heights that are a multiple of 4 but not of 8 (the direct kernel's
+    tile), one and nine images (grids that do not fill the eight-XCD rounding), a 4-row image whose every tile touches both
+    the top and the bottom border """
+    k = _k()
+    w = rnd("w4w", (64, 64, 5, 5), "uniform", (25 * 64) ** -0.5)
+    b = rnd("w4b", (64,), "uniform", 0.1)
+    wp = k.split_conv_weights_wino_f16x3(w.to(DEV))
+    for n, H, W in ((1, 20, 64), (9, 4, 64), (2, 12, 128)):
+        x = rnd(f"w4x{H}", (n, H, W, 64))
+        ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=2)).permute(0, 2, 3, 1)
+        got = k.conv5x5_dec_wino(x.to(DEV), wp, b.to(DEV), relu=True)
+        err = (got.cpu().double() - ref).abs().max().item()
+        print(f"Winograd conv {n} x {H} x {W}: max abs err {err:.2e} at scale {ref.abs().max().item():.3g}")
+        assert err < 3e-6 * ref.abs().max().item(), (n, H, W)
+
+
 def test_conv5x5_dec_wino_collapsed_tail_and_wide_weights():
     """ first-layer (collapsed) mode, the folded decoder tail in the epilogue, and weights far outside the direct
     kernel's |w| < 63 range (the per-row scales are picked from the weights) """
