@@ -31,7 +31,8 @@
 // workgroup measured the same: scripts/probes/retired/conv_wino_wg8.txt).
 // After the last pass the eight M_xi meet through LDS (two rounds of 64 KB, one per pixel half): wave w reads register
 // quad w of all eight rows and both channel halves and forms a 4-row x 8-column x 64-channel block with AT scaled by
-// the inverse operand scales (kernel arguments), adds bias / ReLU and stores (fp32 NHWC, fp32 x 16 pass-major for the
+// the inverse operand scales and the output buffer's scale (kernel arguments) on top of the bias, applies the ReLU and
+// stores (fp32 NHWC, fp32 x 16 pass-major for the
 // next layer of this kernel, fp16 operand planes for conv_f16x3.hip, or -- last hidden layer -- the 36 tap products of
 // the folded decoder tail).
 // Where the time goes (scripts/probes/wino_stamp.hip, TOCVP_WINO_ABLATE): profiles/r05_wino.md.
