@@ -345,3 +345,50 @@ def test_every_knob_is_documented():
     import subprocess
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "list_knobs.py"), "--check"], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_winograd_matrices_of_the_decoder_conv():
+    """ host side of csrc/conv_wino.hip: the output transform the Python side folds into the kernel's coefficients
+    (kernels._WINO_AT), the input transform the kernel applies (BT, restated here from its source comments / code) and the
+    weight transform of its packing kernel (WINO_G, parsed from the source) satisfy the F(4, 5) identity
+    y[a] = sum_k g[k] d[a + k] for every a, and the vertical-only convolution built from them equals torch's conv2d """
+    import re
+    import numpy as np
+    import torch.nn.functional as F
+    from textocvp_amd import kernels as K
+    AT = np.array(K._WINO_AT, dtype=np.float64)
+    BT = np.array([[1, 0, -5.25, 0, 5.25, 0, -1, 0],
+                   [0, 1, 1, -4.25, -4.25, 1, 1, 0],
+                   [0, -1, 1, 4.25, -4.25, -1, 1, 0],
+                   [0, 0.5, 0.25, -2.5, -1.25, 2, 1, 0],
+                   [0, -0.5, 0.25, 2.5, -1.25, -2, 1, 0],
+                   [0, 2, 4, -2.5, -5, 0.5, 1, 0],
+                   [0, -2, 4, 2.5, -5, -0.5, 1, 0],
+                   [0, -1, 0, 5.25, 0, -5.25, 0, 1]], dtype=np.float64)
+    src = open(os.path.join(ROOT, "textocvp_amd", "csrc", "conv_wino.hip")).read()
+    body = src[src.index("WINO_G[NXI][5] = {"):]
+    body = body[:body.index("};")]
+    rows = re.findall(r"\{([^{}]+)\}", body)
+    G = np.array([[eval(tok) for tok in r.split(",")] for r in rows], dtype=np.float64)
+    assert AT.shape == (4, 8) and G.shape == (8, 5)
+    rng = np.random.default_rng(5)
+    g, d = rng.standard_normal(5), rng.standard_normal(8)
+    y = AT @ ((G @ g) * (BT @ d))
+    ref = np.array([sum(g[k] * d[a + k] for k in range(5)) for a in range(4)])
+    assert np.abs(y - ref).max() < 1e-12
+    # |BT| row sums bound the growth of the transformed operand: 15 x 16 x 255.9 < 65504 (the kernel's x 16 scale)
+    assert np.abs(BT).sum(1).max() == 15.0 and 15.0 * 16.0 * 255.9 < 65504.0
+    # the nested form the kernel evaluates (vertical transform, five direct horizontal taps) on a small image
+    w = torch.from_numpy(rng.standard_normal((3, 2, 5, 5)))
+    x = torch.from_numpy(rng.standard_normal((1, 2, 8, 9)))
+    ref2 = F.conv2d(x, w, padding=2)
+    xp = F.pad(x, (2, 2, 2, 2))
+    U = torch.einsum("ak,ockl->aloc", torch.from_numpy(G), w)                     # (8, 5, O, C)
+    out = torch.zeros_like(ref2)
+    for t in range(2):
+        V = torch.einsum("ai,ncix->ancx", torch.from_numpy(BT), xp[:, :, 4 * t:4 * t + 8])      # (8, n, C, W + 4)
+        M = torch.zeros((8, 1, 3, 9), dtype=torch.float64)
+        for dx in range(5):
+            M += torch.einsum("ancx,aoc->anox", V[:, :, :, dx:dx + 9], U[:, dx])
+        out[:, :, 4 * t:4 * t + 4] = torch.einsum("ba,anox->nobx", torch.from_numpy(AT), M)
+    assert (out - ref2).abs().max().item() < 1e-12
