@@ -8,7 +8,11 @@ Compares, on slots of a committed golden fixture and the synthetic weight famili
     fp64 direct (truth) | fp32 direct | split-fp16 direct (simulated) | split-fp16 Winograd (simulated, several
     point sets) -- rendered frames, slot masks and the per-pixel winning slot.
 
-    python scripts/probes/winograd_numerics.py [family] [frames]
+    python scripts/probes/winograd_numerics.py [family] [frames] [only1d]
+
+(third argument: only the 1-D forms -- F(2, 5) / F(4, 5) along y nested with the five direct taps along x, the second of which
+csrc/conv_wino.hip implements -- with scales picked from the data and with the kernel's fixed ones; the matrix core's flush of
+fp16 subnormals is modelled, FLUSH below.)
 """
 import json
 import os
